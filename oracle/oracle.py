@@ -1,0 +1,201 @@
+"""ctypes front end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py, always as the checker.  Nothing under
+stereo_vision_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF_HAMMING = os.path.join(_HERE, "_ref", "libhamming_ref.so")
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref/ when the reference tree is mounted)."""
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
+            os.path.join(_HERE, "sgm_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_HAMMING)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.oracle_census_u32.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
+        L.oracle_hamming_volume_u8.argtypes = [u32p, u32p, C.c_int, C.c_int, C.c_int, u8p]
+        L.oracle_hamming_matrix_u16.argtypes = [u16p, u8p, u8p, C.c_int, C.c_int, C.c_int]
+        for name in ("oracle_aggregate_dir_u32", "oracle_aggregate_dir_u32_edges"):
+            getattr(L, name).argtypes = [u8p] + [C.c_int] * 7 + [u32p]
+        L.oracle_aggregate_dir_f32.argtypes = [f32p] + [C.c_int] * 7 + [f32p]
+        L.oracle_sum_u32.argtypes = [u32p, u32p, C.c_size_t]
+        L.oracle_direction.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_disparity_u16_from_u32.argtypes = [u32p, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
+        L.oracle_disparity_u16_from_f32.argtypes = [f32p, C.c_int, C.c_int, C.c_int, u16p, C.POINTER(C.c_int)]
+        L.oracle_median3_u16.argtypes = [u16p, C.c_int, C.c_int, u16p]
+        L.oracle_data_cost_wta_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        L.oracle_descriptor_cost_f32.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        L.oracle_sgm_census.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 5
+        L.oracle_sgm_census.restype = C.c_int
+        L.oracle_sgm_cost_f32.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4
+        L.oracle_sgm_cost_f32.restype = C.c_int
+        L.oracle_fnv_u16.argtypes = [u16p, C.c_size_t]
+        L.oracle_fnv_u16.restype = C.c_uint64
+        _lib = L
+    return _lib
+
+
+def directions(num_paths):
+    dx, dy = C.c_int(), C.c_int()
+    out = []
+    for k in range(num_paths):
+        assert lib().oracle_direction(num_paths, k, C.byref(dx), C.byref(dy)) == 0
+        out.append((dx.value, dy.value))
+    return out
+
+
+def census(img, wsz):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    m = (wsz - 1) // 2
+    out = np.empty((H - 2 * m, W - 2 * m), np.uint32)
+    lib().oracle_census_u32(img, W, H, W, wsz, out)
+    return out
+
+
+def hamming_volume(cl, cr, D):
+    h, w = cl.shape
+    out = np.empty((h, w, D), np.uint8)
+    lib().oracle_hamming_volume_u8(np.ascontiguousarray(cl), np.ascontiguousarray(cr), w, h, D, out)
+    return out
+
+
+def hamming_matrix(a, b):
+    """a: (na, ncodes) uint8, b: (nb, ncodes) uint8 -> (nb, na) uint16."""
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.empty((b.shape[0], a.shape[0]), np.uint16)
+    lib().oracle_hamming_matrix_u16(out, a, b, a.shape[0], b.shape[0], a.shape[1])
+    return out
+
+
+def ref_hamming_matrix(a, b):
+    """The reference's own core/hamming.c compute_hamming (oracle/_ref)."""
+    if not os.path.exists(_REF_HAMMING):
+        return None
+    L = C.CDLL(_REF_HAMMING)
+    L.compute_hamming.argtypes = [u16p, u8p, u8p, C.c_int, C.c_int, C.c_int]
+    L.compute_hamming.restype = None
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.empty((b.shape[0], a.shape[0]), np.uint16)
+    L.compute_hamming(out, a, b, a.shape[0], b.shape[0], a.shape[1])
+    return out
+
+
+def aggregate_dir_u32(Cvol, dx, dy, P1, P2, buf, edges=False):
+    h, w, D = Cvol.shape
+    fn = lib().oracle_aggregate_dir_u32_edges if edges else lib().oracle_aggregate_dir_u32
+    fn(Cvol, w, h, D, dx, dy, P1, P2, buf)
+    return buf
+
+
+def aggregate_dir_f32(Cvol, dx, dy, P1, P2, buf):
+    h, w, D = Cvol.shape
+    lib().oracle_aggregate_dir_f32(Cvol, w, h, D, dx, dy, P1, P2, buf)
+    return buf
+
+
+def disparity_from_u32(S, m):
+    h, w, D = S.shape
+    out = np.empty((h + 2 * m, w + 2 * m), np.uint16)
+    lib().oracle_disparity_u16_from_u32(S, w, h, D, m, out)
+    return out
+
+
+def median3(img):
+    img = np.ascontiguousarray(img, np.uint16)
+    out = np.empty_like(img)
+    lib().oracle_median3_u16(img, img.shape[1], img.shape[0], out)
+    return out
+
+
+def data_cost_wta(Cvol, m):
+    h, w, D = Cvol.shape
+    out = np.empty((h + 2 * m, w + 2 * m), np.uint8)
+    lib().oracle_data_cost_wta_u8(np.ascontiguousarray(Cvol), w, h, D, m, out)
+    return out
+
+
+def descriptor_cost(fl, fr, D):
+    h, w, K = fl.shape
+    out = np.empty((h, w, D), np.float32)
+    lib().oracle_descriptor_cost_f32(np.ascontiguousarray(fl, np.float32), np.ascontiguousarray(fr, np.float32),
+                                     w, h, K, D, out)
+    return out
+
+
+def sgm_census(left, right, D, wsz, P1, P2, num_paths=8, reset_between_dirs=False, taps=False):
+    """recon::StereoSGM::compute restated.  Returns disp (H, W) uint16, or a dict
+    with the stage taps when taps=True."""
+    left = np.ascontiguousarray(left, np.uint8)
+    right = np.ascontiguousarray(right, np.uint8)
+    H, W = left.shape
+    m = (wsz - 1) // 2
+    h, w = H - 2 * m, W - 2 * m
+    disp = np.empty((H, W), np.uint16)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    Cv = S = raw = lmax = None
+    if taps:
+        Cv = np.empty((h, w, D), np.uint8)
+        S = np.empty((h, w, D), np.uint32)
+        raw = np.empty((H, W), np.uint16)
+        lmax = np.zeros(num_paths, np.uint32)
+    rc = lib().oracle_sgm_census(ptr(left), ptr(right), W, H, W, D, wsz, P1, P2, num_paths,
+                                 int(bool(reset_between_dirs)), ptr(disp), ptr(Cv), ptr(S), ptr(raw), ptr(lmax))
+    if rc != 0:
+        raise ValueError("oracle_sgm_census: bad arguments")
+    if taps:
+        return dict(disp=disp, C=Cv, S=S, raw=raw, Lmax=lmax)
+    return disp
+
+
+def sgm_cost_f32(Cvol, P1, P2, num_paths=8, taps=False):
+    """recon::SGM::Compute from the float data-cost volume on. (h, w) uint16."""
+    Cvol = np.ascontiguousarray(Cvol, np.float32)
+    h, w, D = Cvol.shape
+    disp = np.empty((h, w), np.uint16)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    S = raw = None
+    nundef = C.c_int(0)
+    if taps:
+        S = np.empty((h, w, D), np.float32)
+        raw = np.empty((h, w), np.uint16)
+    rc = lib().oracle_sgm_cost_f32(ptr(Cvol), w, h, D, P1, P2, num_paths, ptr(disp), ptr(S), ptr(raw),
+                                   C.cast(C.byref(nundef), C.c_void_p))
+    if rc != 0:
+        raise ValueError("oracle_sgm_cost_f32: bad arguments")
+    if taps:
+        return dict(disp=disp, S=S, raw=raw, n_undefined=nundef.value)
+    return disp
+
+
+def fnv_u16(img):
+    img = np.ascontiguousarray(img, np.uint16)
+    return int(lib().oracle_fnv_u16(img.reshape(-1), img.size))

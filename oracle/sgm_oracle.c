@@ -1,0 +1,580 @@
+/*
+ * sgm_oracle.c -- CPU restatement of the reference's semi-global matching path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library, and only as the checker.  The product
+ * path (libsgmx.so, HIP) never links, loads or calls anything in oracle/.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the upstream tree, reconstruction/base/ unless noted).  Arithmetic types are
+ * the reference's own: uint8 data cost, uint32 aggregated cost for the census
+ * build (stereo_sgm.h:35-39), float/float for the CNN build (sgm.h:43-46).
+ *
+ * Parity pinning: the reference's class needs OpenCV/Eigen/boost headers that
+ * this image lacks, so it is NOT rebuilt here.  The restatement is pinned by
+ * the known answers SURVEY.md section 8c records for the reference's own
+ * fixtures (tests/test_oracle_golden.py), and core/hamming.c -- which does
+ * compile from its own source -- pins the Hamming primitive (oracle/Makefile,
+ * target _ref/libhamming_ref.so).
+ *
+ * Layouts: images row-major uint8; census uint32 [H'][W']; volumes [y][x][d]
+ * with d fastest, flat.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* Matching cost                                                       */
+/* ------------------------------------------------------------------ */
+
+/* stereo_costs.cc:36-61 census_transform: window rows y..y+wsz-1 and columns
+ * x..x+wsz-1 of the uncropped image, centre (y+m, x+m) skipped, row-major,
+ * code = (code << 1) + (I(q) > I(c)) in a uint32 that silently drops high
+ * bits for windows with more than 33 taps. Output is (H-2m) x (W-2m). */
+ORACLE_API void oracle_census_u32(const uint8_t *img, int W, int H, int stride, int wsz, uint32_t *out)
+{
+    const int m = (wsz - 1) / 2;
+    const int ow = W - 2 * m, oh = H - 2 * m;
+    for (int y = 0; y < oh; y++)
+        for (int x = 0; x < ow; x++) {
+            const int cy = y + m, cx = x + m;
+            const uint8_t c = img[(size_t)cy * stride + cx];
+            uint32_t code = 0;
+            for (int py = y; py <= y + wsz - 1; py++)
+                for (int px = x; px <= x + wsz - 1; px++) {
+                    if (px == cx && py == cy)
+                        continue;
+                    code <<= 1;
+                    code += img[(size_t)py * stride + px] > c ? 1u : 0u;
+                }
+            out[(size_t)y * ow + x] = code;
+        }
+}
+
+/* stereo_costs.h:120-132 hamming_dist<uint32_t>: Kernighan bit count of x^y,
+ * returned as uint8. */
+static uint8_t hamming_u32(uint32_t a, uint32_t b)
+{
+    uint32_t v = a ^ b;
+    uint8_t n = 0;
+    while (v) {
+        ++n;
+        v &= v - 1;
+    }
+    return n;
+}
+
+/* stereo_sgm.cc:43 (init to numeric_limits<uint8>::max()) and :75-101 (the
+ * data-cost loop): C[y][x][d] = hamming(cL[y][x], cR[y][x-d]) for x >= d,
+ * 255 otherwise. */
+ORACLE_API void oracle_hamming_volume_u8(const uint32_t *cl, const uint32_t *cr, int w, int h, int D, uint8_t *C)
+{
+    memset(C, 0xFF, (size_t)w * h * D);
+    for (int y = 0; y < h; y++)
+        for (int d = 0; d < D; d++)
+            for (int x = d; x < w; x++)
+                C[((size_t)y * w + x) * D + d] = hamming_u32(cl[(size_t)y * w + x], cr[(size_t)y * w + x - d]);
+}
+
+/* core/hamming.c:104-116 (hamming: per-byte bit-count table summed into a
+ * uint16) and :215-236 (compute_hamming: dis[j*na + i] = hamming(a_i, b_j);
+ * the 4/8/16-byte fast paths give the same numbers). */
+ORACLE_API void oracle_hamming_matrix_u16(uint16_t *dis, const uint8_t *a, const uint8_t *b, int na, int nb, int ncodes)
+{
+    for (int j = 0; j < nb; j++)
+        for (int i = 0; i < na; i++) {
+            uint16_t s = 0;
+            for (int k = 0; k < ncodes; k++) {
+                uint8_t v = a[(size_t)i * ncodes + k] ^ b[(size_t)j * ncodes + k];
+                while (v) {
+                    ++s;
+                    v &= (uint8_t)(v - 1);
+                }
+            }
+            dis[(size_t)j * na + i] = s;
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* Path aggregation, census build (uint8 cost, uint32 path cost)       */
+/* ------------------------------------------------------------------ */
+
+/* stereo_sgm.h:119-147 aggregate_path (+ get_min :197-207, copy_vector
+ * :94-103).  out may not alias prior. */
+static void path_step_u32(const uint32_t *prior, const uint8_t *local, uint32_t *out, int D, int P1, int P2)
+{
+    uint32_t mp = prior[0];
+    for (int i = 1; i < D; i++)
+        if (prior[i] < mp)
+            mp = prior[i];
+    for (int d = 0; d < D; d++) {
+        uint32_t e = mp + (uint32_t)P2;
+        if (prior[d] < e)
+            e = prior[d];
+        if (d > 0 && prior[d - 1] + (uint32_t)P1 < e)
+            e = prior[d - 1] + (uint32_t)P1;
+        if (d < D - 1 && prior[d + 1] + (uint32_t)P1 < e)
+            e = prior[d + 1] + (uint32_t)P1;
+        out[d] = (uint32_t)local[d] + (e - mp);
+    }
+}
+
+/* stereo_sgm.cc:191-268 aggregate_costs for one direction (dx,dy); the
+ * predecessor of (y,x) is (y-dy, x-dx) (:209).  The reference walks the
+ * image edge by edge; every pixel is visited exactly once and depends only
+ * on its predecessor, so the same result is obtained by walking each path
+ * from its start pixel.  A pixel is a start pixel iff its predecessor lies
+ * outside the image; there the reference does buf += C (:201,218,236,254)
+ * on a buffer it never clears between directions (stereo_sgm.cc:46,
+ * :142 commented out) -- the carry-over the callers below reproduce by
+ * passing the same buf to successive calls.  Elsewhere buf is overwritten. */
+ORACLE_API void oracle_aggregate_dir_u32(const uint8_t *C, int w, int h, int D, int dx, int dy, int P1, int P2,
+                                         uint32_t *buf)
+{
+    for (int y0 = 0; y0 < h; y0++)
+        for (int x0 = 0; x0 < w; x0++) {
+            const int py = y0 - dy, px = x0 - dx;
+            if (py >= 0 && py < h && px >= 0 && px < w)
+                continue; /* not a start pixel */
+            size_t p = ((size_t)y0 * w + x0) * D;
+            for (int d = 0; d < D; d++)
+                buf[p + d] += C[p + d];
+            int y = y0 + dy, x = x0 + dx;
+            while (y >= 0 && y < h && x >= 0 && x < w) {
+                size_t q = ((size_t)y * w + x) * D;
+                path_step_u32(buf + p, C + q, buf + q, D, P1, P2);
+                p = q;
+                y += dy;
+                x += dx;
+            }
+        }
+}
+
+/* A second, independent statement of the same sweep that follows the
+ * reference's four edge blocks literally (stereo_sgm.cc:197-267), used by
+ * the tests to cross-check the path-walk form above on small inputs. */
+ORACLE_API void oracle_aggregate_dir_u32_edges(const uint8_t *C, int w, int h, int D, int dx, int dy, int P1, int P2,
+                                               uint32_t *buf)
+{
+#define AT(yy, xx) (((size_t)(yy) * w + (xx)) * D)
+#define START(yy, xx)                                                                                                  \
+    do {                                                                                                               \
+        for (int d_ = 0; d_ < D; d_++)                                                                                 \
+            buf[AT(yy, xx) + d_] += C[AT(yy, xx) + d_];                                                                \
+    } while (0)
+#define STEP(yy, xx) path_step_u32(buf + AT((yy) - dy, (xx) - dx), C + AT(yy, xx), buf + AT(yy, xx), D, P1, P2)
+    if (dx > 0) {
+        for (int y = 0; y < h; y++)
+            START(y, 0);
+        for (int x = 1; x < w; x++) {
+            int a = dy * x > 0 ? dy * x : 0;
+            int b = h + dy * x < h ? h + dy * x : h;
+            for (int y = a; y < b; y++)
+                STEP(y, x);
+        }
+    }
+    if (dy > 0) {
+        const int s = dx <= 0 ? 0 : 1;
+        for (int x = s; x < w; x++)
+            START(0, x);
+        for (int y = 1; y < h; y++) {
+            int a = s + dx * y > s ? s + dx * y : s;
+            int b = w + dx * y < w ? w + dx * y : w;
+            for (int x = a; x < b; x++)
+                STEP(y, x);
+        }
+    }
+    if (dx < 0) {
+        const int s = dy <= 0 ? 0 : 1;
+        for (int y = s; y < h; y++)
+            START(y, w - 1);
+        for (int x = w - 2; x >= 0; x--) {
+            int k = x - w + 1;
+            int a = s - dy * k > s ? s - dy * k : s;
+            int b = h - dy * k < h ? h - dy * k : h;
+            for (int y = a; y < b; y++)
+                STEP(y, x);
+        }
+    }
+    if (dy < 0) {
+        const int s = dx <= 0 ? 0 : 1;
+        const int e = dx >= 0 ? w : w - 1;
+        for (int x = s; x < e; x++)
+            START(h - 1, x);
+        for (int y = h - 2; y >= 0; y--) {
+            int k = y - h + 1;
+            int a = s - dx * k > s ? s - dx * k : s;
+            int b = e - dx * k < e ? e - dx * k : e;
+            for (int x = a; x < b; x++)
+                STEP(y, x);
+        }
+    }
+#undef AT
+#undef START
+#undef STEP
+}
+
+/* stereo_sgm.h:85-92,105-117 sum_costs: S += buf. */
+ORACLE_API void oracle_sum_u32(const uint32_t *buf, uint32_t *S, size_t n)
+{
+    for (size_t i = 0; i < n; i++)
+        S[i] += buf[i];
+}
+
+/* Direction schedule.  8 paths: the double loop at stereo_sgm.cc:120-122
+ * (x outer, y inner, (0,0) skipped).  4 paths: its axis-aligned subset in the
+ * same order, sharing one buffer (BASELINE config 1). */
+static const int DIRS8[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}};
+static const int DIRS4[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
+
+ORACLE_API int oracle_direction(int num_paths, int k, int *dx, int *dy)
+{
+    if (num_paths == 8 && k >= 0 && k < 8) {
+        *dx = DIRS8[k][0];
+        *dy = DIRS8[k][1];
+        return 0;
+    }
+    if (num_paths == 4 && k >= 0 && k < 4) {
+        *dx = DIRS4[k][0];
+        *dy = DIRS4[k][1];
+        return 0;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------ */
+/* WTA + left-right check + subpixel                                   */
+/* ------------------------------------------------------------------ */
+
+/* stereo_sgm.h:275-317 get_disparity_image_uint16 with find_min_disp
+ * (:209-217) and find_min_disp_right (:229-241).  Output is (h+2m) x (w+2m),
+ * zero border of width m. */
+ORACLE_API void oracle_disparity_u16_from_u32(const uint32_t *S, int w, int h, int D, int m, uint16_t *out)
+{
+    const int OW = w + 2 * m, OH = h + 2 * m;
+    memset(out, 0, (size_t)OW * OH * sizeof(uint16_t));
+    for (int y = 0; y < h; y++) {
+        const uint32_t *row = S + (size_t)y * w * D;
+        for (int x = 0; x < w; x++) {
+            const uint32_t *v = row + (size_t)x * D;
+            int d = 0;
+            for (int i = 1; i < D; i++)
+                if (v[i] < v[d])
+                    d = i;
+            uint16_t *o = out + (size_t)(m + y) * OW + (m + x);
+            if (x - d < 0) {
+                *o = 0;
+                continue;
+            }
+            const int xr = x - d;
+            int dr = 0;
+            const int lim = D < w - xr ? D : w - xr;
+            for (int i = 1; i < lim; i++)
+                if (row[(size_t)(xr + i) * D + i] < row[(size_t)(xr + dr) * D + dr])
+                    dr = i;
+            if (abs(d - dr) > 2) {
+                *o = 0;
+                continue;
+            }
+            if (d >= 1 && d < D - 1) {
+                const float cl = (float)v[d - 1], cc = (float)v[d], cr = (float)v[d + 1];
+                float ds; /* float32 intermediates; built with -ffp-contract=off */
+                if (cr < cl)
+                    ds = 0.5f * (cr - cl) / (cc - cl);
+                else
+                    ds = 0.5f * (cr - cl) / (cc - cr);
+                const float dsub = (float)d + ds; /* int + float is float arithmetic (:309) */
+                *o = (uint16_t)round(256.0 * (double)dsub);
+            } else {
+                *o = (uint16_t)round(256.0 * d);
+            }
+        }
+    }
+}
+
+/* cv::medianBlur(disp, disp, 3) at stereo_sgm.cc:187 / sgm.cc:172 -- OpenCV is
+ * not part of the reference tree; its published semantics for ksize 3 on
+ * CV_16U: median of the 3x3 neighbourhood with replicated border, computed
+ * from a copy of the input (the in-place call clones). */
+ORACLE_API void oracle_median3_u16(const uint16_t *in, int W, int H, uint16_t *out)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            uint16_t v[9];
+            int n = 0;
+            for (int j = -1; j <= 1; j++)
+                for (int i = -1; i <= 1; i++) {
+                    int yy = y + j, xx = x + i;
+                    yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+                    xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                    v[n++] = in[(size_t)yy * W + xx];
+                }
+            for (int a = 1; a < 9; a++) { /* insertion sort */
+                uint16_t t = v[a];
+                int b = a - 1;
+                while (b >= 0 && v[b] > t) {
+                    v[b + 1] = v[b];
+                    b--;
+                }
+                v[b + 1] = t;
+            }
+            out[(size_t)y * W + x] = v[4];
+        }
+}
+
+/* stereo_sgm.h:243-257 GetDisparityImage: WTA on the raw data cost, 8-bit,
+ * padded by m (the debug image the reference writes at stereo_sgm.cc:184-185). */
+ORACLE_API void oracle_data_cost_wta_u8(const uint8_t *C, int w, int h, int D, int m, uint8_t *out)
+{
+    const int OW = w + 2 * m, OH = h + 2 * m;
+    memset(out, 0, (size_t)OW * OH);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *v = C + ((size_t)y * w + x) * D;
+            int d = 0;
+            for (int i = 1; i < D; i++)
+                if (v[i] < v[d])
+                    d = i;
+            out[(size_t)(m + y) * OW + (m + x)] = (uint8_t)d;
+        }
+}
+
+/* stereo_sgm.cc:15-188 StereoSGM::compute (COST_CENSUS build).  Optional taps
+ * (may be NULL): C_out [h][w][D] uint8, S_out [h][w][D] uint32, raw_out the
+ * disparity image before the median, Lmax[num_paths] the maximum path cost
+ * per direction.  reset_between_dirs = 1 clears the path buffer before every
+ * direction, which is NOT what the reference does; it exists only so the tests
+ * can show that the carry-over is output-visible.  Returns 0, or -1 on bad
+ * arguments / allocation failure. */
+ORACLE_API int oracle_sgm_census(const uint8_t *left, const uint8_t *right, int W, int H, int stride, int D, int wsz,
+                                 int P1, int P2, int num_paths, int reset_between_dirs, uint16_t *disp,
+                                 uint8_t *C_out, uint32_t *S_out, uint16_t *raw_out, uint32_t *Lmax)
+{
+    const int m = (wsz - 1) / 2;
+    const int w = W - 2 * m, h = H - 2 * m;
+    if (w <= 0 || h <= 0 || D < 1 || (num_paths != 4 && num_paths != 8))
+        return -1;
+    const size_t npix = (size_t)w * h, nvox = npix * D;
+    uint32_t *cl = malloc(npix * 4), *cr = malloc(npix * 4);
+    uint8_t *C = malloc(nvox);
+    uint32_t *buf = calloc(nvox, 4), *S = calloc(nvox, 4);
+    uint16_t *raw = malloc((size_t)W * H * 2);
+    int rc = -1;
+    if (cl && cr && C && buf && S && raw) {
+        oracle_census_u32(left, W, H, stride, wsz, cl);
+        oracle_census_u32(right, W, H, stride, wsz, cr);
+        oracle_hamming_volume_u8(cl, cr, w, h, D, C);
+        for (int k = 0; k < num_paths; k++) {
+            int dx, dy;
+            oracle_direction(num_paths, k, &dx, &dy);
+            if (reset_between_dirs)
+                memset(buf, 0, nvox * 4);
+            oracle_aggregate_dir_u32(C, w, h, D, dx, dy, P1, P2, buf);
+            oracle_sum_u32(buf, S, nvox);
+            if (Lmax) {
+                uint32_t mx = 0;
+                for (size_t i = 0; i < nvox; i++)
+                    if (buf[i] > mx)
+                        mx = buf[i];
+                Lmax[k] = mx;
+            }
+        }
+        oracle_disparity_u16_from_u32(S, w, h, D, m, raw);
+        oracle_median3_u16(raw, W, H, disp);
+        if (C_out)
+            memcpy(C_out, C, nvox);
+        if (S_out)
+            memcpy(S_out, S, nvox * 4);
+        if (raw_out)
+            memcpy(raw_out, raw, (size_t)W * H * 2);
+        rc = 0;
+    }
+    free(cl);
+    free(cr);
+    free(C);
+    free(buf);
+    free(S);
+    free(raw);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* Float (CNN / precomputed data cost) build                           */
+/* ------------------------------------------------------------------ */
+
+/* sgm.h:129-157 aggregate_path, float twin: error = min_prior + P2 is a
+ * float + int addition, prior[d+-1] + P1 likewise, and the result is
+ * local + (error - min_prior), in this order. */
+static void path_step_f32(const float *prior, const float *local, float *out, int D, int P1, int P2)
+{
+    float mp = prior[0];
+    for (int i = 1; i < D; i++)
+        if (prior[i] < mp)
+            mp = prior[i];
+    for (int d = 0; d < D; d++) {
+        float e = mp + (float)P2;
+        if (prior[d] < e)
+            e = prior[d];
+        if (d > 0) {
+            const float t = prior[d - 1] + (float)P1;
+            if (t < e)
+                e = t;
+        }
+        if (d < D - 1) {
+            const float t = prior[d + 1] + (float)P1;
+            if (t < e)
+                e = t;
+        }
+        const float diff = e - mp;
+        out[d] = local[d] + diff;
+    }
+}
+
+/* sgm.cc:177-254 aggregate_costs, float twin of the sweep above. */
+ORACLE_API void oracle_aggregate_dir_f32(const float *C, int w, int h, int D, int dx, int dy, int P1, int P2, float *buf)
+{
+    for (int y0 = 0; y0 < h; y0++)
+        for (int x0 = 0; x0 < w; x0++) {
+            const int py = y0 - dy, px = x0 - dx;
+            if (py >= 0 && py < h && px >= 0 && px < w)
+                continue;
+            size_t p = ((size_t)y0 * w + x0) * D;
+            for (int d = 0; d < D; d++)
+                buf[p + d] += C[p + d]; /* sgm.h:95-102 sum_vectors */
+            int y = y0 + dy, x = x0 + dx;
+            while (y >= 0 && y < h && x >= 0 && x < w) {
+                size_t q = ((size_t)y * w + x) * D;
+                path_step_f32(buf + p, C + q, buf + q, D, P1, P2);
+                p = q;
+                y += dy;
+                x += dx;
+            }
+        }
+}
+
+/* sgm.h:285-332 get_disparity_image_uint16 (CNN build): same decisions as the
+ * census version but the output is h x w with NO padding (:291).  A NaN or
+ * out-of-range subpixel value is undefined behaviour in the reference's
+ * uint16 cast; here it yields 0 and is counted in *n_undefined (may be NULL)
+ * so tests can exclude those pixels. */
+ORACLE_API void oracle_disparity_u16_from_f32(const float *S, int w, int h, int D, uint16_t *out, int *n_undefined)
+{
+    int undef = 0;
+    for (int y = 0; y < h; y++) {
+        const float *row = S + (size_t)y * w * D;
+        for (int x = 0; x < w; x++) {
+            const float *v = row + (size_t)x * D;
+            int d = 0;
+            for (int i = 1; i < D; i++)
+                if (v[i] < v[d])
+                    d = i;
+            uint16_t *o = out + (size_t)y * w + x;
+            if (x - d < 0) {
+                *o = 0;
+                continue;
+            }
+            const int xr = x - d;
+            int dr = 0;
+            const int lim = D < w - xr ? D : w - xr;
+            for (int i = 1; i < lim; i++)
+                if (row[(size_t)(xr + i) * D + i] < row[(size_t)(xr + dr) * D + dr])
+                    dr = i;
+            if (abs(d - dr) > 2) {
+                *o = 0;
+                continue;
+            }
+            if (d >= 1 && d < D - 1) {
+                const float cl = v[d - 1], cc = v[d], cr = v[d + 1];
+                float ds;
+                if (cr < cl)
+                    ds = 0.5f * (cr - cl) / (cc - cl);
+                else
+                    ds = 0.5f * (cr - cl) / (cc - cr);
+                const float dsub = (float)d + ds;
+                const double r = round(256.0 * (double)dsub);
+                if (!(r >= 0.0 && r <= 65535.0)) {
+                    *o = 0;
+                    undef++;
+                } else
+                    *o = (uint16_t)r;
+            } else {
+                *o = (uint16_t)round(256.0 * d);
+            }
+        }
+    }
+    if (n_undefined)
+        *n_undefined = undef;
+}
+
+/* sgm.cc:76-84: C[y][x][d] = ||fL[y][x] - fR[y][x-d]||_2 for x >= d, FLT_MAX
+ * (sgm.cc:55) otherwise.  Eigen's .norm() reduction order is build-dependent
+ * (parity unpinned for this function); a plain left-to-right
+ * float sum of squares followed by sqrtf is used here. */
+ORACLE_API void oracle_descriptor_cost_f32(const float *fl, const float *fr, int w, int h, int K, int D, float *C)
+{
+    for (size_t i = 0; i < (size_t)w * h * D; i++)
+        C[i] = FLT_MAX;
+    for (int y = 0; y < h; y++)
+        for (int d = 0; d < D; d++)
+            for (int x = d; x < w; x++) {
+                const float *a = fl + ((size_t)y * w + x) * K;
+                const float *b = fr + ((size_t)y * w + x - d) * K;
+                float s = 0.f;
+                for (int k = 0; k < K; k++) {
+                    const float t = a[k] - b[k];
+                    s += t * t;
+                }
+                C[((size_t)y * w + x) * D + d] = sqrtf(s);
+            }
+}
+
+/* sgm.cc:14-174 SGM::Compute from the point where the float data cost exists
+ * (the precomputed-volume entry): aggregate over the same direction schedule
+ * with the same never-cleared buffer (sgm.cc:103-118), sum, disparity without
+ * padding, median.  S_out (may be NULL) receives the summed volume. */
+ORACLE_API int oracle_sgm_cost_f32(const float *C, int w, int h, int D, int P1, int P2, int num_paths, uint16_t *disp,
+                                   float *S_out, uint16_t *raw_out, int *n_undefined)
+{
+    if (w <= 0 || h <= 0 || D < 1 || (num_paths != 4 && num_paths != 8))
+        return -1;
+    const size_t nvox = (size_t)w * h * D;
+    float *buf = calloc(nvox, 4), *S = calloc(nvox, 4);
+    uint16_t *raw = malloc((size_t)w * h * 2);
+    int rc = -1;
+    if (buf && S && raw) {
+        for (int k = 0; k < num_paths; k++) {
+            int dx, dy;
+            oracle_direction(num_paths, k, &dx, &dy);
+            oracle_aggregate_dir_f32(C, w, h, D, dx, dy, P1, P2, buf);
+            for (size_t i = 0; i < nvox; i++) {
+                S[i] = S[i] + buf[i];
+            }
+        }
+        oracle_disparity_u16_from_f32(S, w, h, D, raw, n_undefined);
+        oracle_median3_u16(raw, w, h, disp);
+        if (S_out)
+            memcpy(S_out, S, nvox * 4);
+        if (raw_out)
+            memcpy(raw_out, raw, (size_t)w * h * 2);
+        rc = 0;
+    }
+    free(buf);
+    free(S);
+    free(raw);
+    return rc;
+}
+
+/* Checksum SURVEY.md 8c quotes its known answers in: FNV-1a style, one update
+ * per uint16 pixel value, h0 = 1469598103934665603, prime 1099511628211. */
+ORACLE_API uint64_t oracle_fnv_u16(const uint16_t *v, size_t n)
+{
+    uint64_t hsh = 1469598103934665603ULL;
+    for (size_t i = 0; i < n; i++)
+        hsh = (hsh ^ (uint64_t)v[i]) * 1099511628211ULL;
+    return hsh;
+}

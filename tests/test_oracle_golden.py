@@ -1,0 +1,171 @@
+"""Pins the CPU oracle (oracle/sgm_oracle.c) to the reference.
+
+Known answers: SURVEY.md section 8c -- outputs of the reference's own
+recon::StereoSGM::compute (stereo_sgm.cc:15-188) on the reference's own fixtures
+reconstruction/test/{tsukuba_l,tsukuba_r,left_000087,right_000087}.png, P1=3, P2=60,
+recorded as sum / non-zero count / 64-bit FNV-style hash over the uint16 output.
+The Hamming primitive is additionally pinned against the reference's core/hamming.c
+compiled as-is (oracle/_ref/libhamming_ref.so) when that build is present.
+"""
+import numpy as np
+import pytest
+
+# (fixture, D, wsz, num_paths) -> (sum, nonzero, fnv)
+KNOWN = {
+    ("tsukuba", 16, 5, 8): (177734591, 105163, 0xFB2353D52A6B2EE2),
+    ("tsukuba", 16, 5, 4): (177041394, 104788, 0x456B80E5D90EF209),
+    ("tsukuba", 16, 3, 8): (178288796, 106672, 0xDE77C8FF19A1052F),
+    ("kitti", 128, 5, 8): (2795828975, 415382, 0x4ACA717F5249B4D4),
+    ("kitti", 128, 5, 4): (2783554156, 411634, 0x1124DB038A65BA05),
+    ("kitti", 128, 3, 8): (2656778054, 412072, 0xE894A754560277B3),
+}
+# with the per-direction reset the reference does NOT do (regression sentinels for the carry-over)
+RESET_FNV = {("tsukuba", 16, 5, 8): 0xC7390A4498379D69, ("kitti", 128, 5, 8): 0x3858AD135DE9605A}
+
+
+@pytest.mark.parametrize("key", sorted(KNOWN))
+def test_known_answers(oracle, tsukuba, kitti, key):
+    name, D, wsz, paths = key
+    left, right = tsukuba if name == "tsukuba" else kitti
+    disp = oracle.sgm_census(left, right, D, wsz, 3, 60, paths)
+    s, nz, fnv = KNOWN[key]
+    assert disp.shape == left.shape and disp.dtype == np.uint16
+    assert int(disp.sum(dtype=np.uint64)) == s
+    assert int(np.count_nonzero(disp)) == nz
+    assert oracle.fnv_u16(disp) == fnv
+
+
+def test_carry_over_is_output_visible(oracle, tsukuba):
+    key = ("tsukuba", 16, 5, 8)
+    disp = oracle.sgm_census(*tsukuba, 16, 5, 3, 60, 8, reset_between_dirs=True)
+    assert oracle.fnv_u16(disp) == RESET_FNV[key]
+    assert oracle.fnv_u16(disp) != KNOWN[key][2]
+
+
+def test_kitti_per_direction_maxima(oracle, kitti):
+    # per-direction max L = 315,315,570,570,570,825,1080,1335; max S = 5325
+    r = oracle.sgm_census(*kitti, 128, 5, 3, 60, 8, taps=True)
+    assert r["Lmax"].tolist() == [315, 315, 570, 570, 570, 825, 1080, 1335]
+    assert int(r["S"].max()) == 5325
+
+
+def test_fnv_matches_independent_python():
+    from oracle import oracle as o
+    v = np.array([0, 1, 65535, 256, 77], np.uint16)
+    h = 1469598103934665603
+    for x in v.tolist():
+        h = ((h ^ x) * 1099511628211) % (1 << 64)
+    assert o.fnv_u16(v) == h
+
+
+@pytest.mark.parametrize("dx,dy", [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("shape", [(7, 11, 5), (11, 7, 4), (1, 9, 3), (9, 1, 3), (2, 2, 2), (1, 1, 2)])
+def test_path_walk_equals_edge_walk(oracle, dx, dy, shape):
+    """The oracle's path-walk sweep and the literal restatement of the reference's four
+    edge blocks (stereo_sgm.cc:197-267) agree, including on a dirty carry-over buffer."""
+    h, w, D = shape
+    rng = np.random.default_rng(h * 100 + w * 10 + D)
+    C = rng.integers(0, 256, size=(h, w, D)).astype(np.uint8)
+    buf0 = rng.integers(0, 500, size=(h, w, D)).astype(np.uint32)
+    a = oracle.aggregate_dir_u32(C, dx, dy, 3, 20, buf0.copy())
+    b = oracle.aggregate_dir_u32(C, dx, dy, 3, 20, buf0.copy(), edges=True)
+    assert np.array_equal(a, b)
+
+
+def _py_path_step(prior, local, P1, P2):
+    D = len(prior)
+    mp = min(prior)
+    out = []
+    for d in range(D):
+        e = min(mp + P2, prior[d])
+        if d > 0:
+            e = min(e, prior[d - 1] + P1)
+        if d < D - 1:
+            e = min(e, prior[d + 1] + P1)
+        out.append(local[d] + e - mp)
+    return out
+
+
+def test_aggregate_against_pure_python(oracle):
+    """Horizontal left-to-right sweep against a direct transcription of the recurrence
+    in stereo_sgm.h:119-147 (pure Python, tiny case)."""
+    rng = np.random.default_rng(5)
+    h, w, D = 3, 6, 7
+    C = rng.integers(0, 40, size=(h, w, D)).astype(np.uint8)
+    buf = oracle.aggregate_dir_u32(C, 1, 0, 2, 9, np.zeros((h, w, D), np.uint32))
+    for y in range(h):
+        prior = C[y, 0].astype(int).tolist()
+        assert buf[y, 0].tolist() == prior
+        for x in range(1, w):
+            prior = _py_path_step(prior, C[y, x].astype(int).tolist(), 2, 9)
+            assert buf[y, x].tolist() == prior
+
+
+def test_census_bit_order_and_wrap(oracle):
+    img = np.arange(49, dtype=np.uint8).reshape(7, 7)
+    # 3x3: neighbours in row-major order, centre skipped, MSB first
+    c3 = oracle.census(img, 3)
+    assert c3.shape == (5, 5)
+    assert int(c3[0, 0]) == 0b00001111  # the 4 later neighbours are brighter
+    # 7x7 has 48 taps: only the low 32 bits survive (stereo_costs.cc:55)
+    c7 = oracle.census(img, 7)
+    assert c7.shape == (1, 1)
+    assert int(c7[0, 0]) == (1 << 24) - 1
+    # wsz=1: no taps, zero code, no crop
+    assert not oracle.census(img, 1).any() and oracle.census(img, 1).shape == (7, 7)
+
+
+def test_hamming_volume_invalid_is_255(oracle):
+    rng = np.random.default_rng(2)
+    cl = rng.integers(0, 1 << 24, size=(4, 9)).astype(np.uint32)
+    cr = rng.integers(0, 1 << 24, size=(4, 9)).astype(np.uint32)
+    C = oracle.hamming_volume(cl, cr, 6)
+    for x in range(9):
+        for d in range(6):
+            if d > x:
+                assert (C[:, x, d] == 255).all()
+            else:
+                want = [bin(int(a) ^ int(b)).count("1") for a, b in zip(cl[:, x], cr[:, x - d])]
+                assert C[:, x, d].tolist() == want
+
+
+@pytest.mark.parametrize("ncodes", [4, 8, 16, 5])
+def test_hamming_matrix_vs_reference_build(oracle, ncodes):
+    """oracle_hamming_matrix_u16 == core/hamming.c compute_hamming (reference build)."""
+    rng = np.random.default_rng(ncodes)
+    a = rng.integers(0, 256, size=(37, ncodes)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(23, ncodes)).astype(np.uint8)
+    mine = oracle.hamming_matrix(a, b)
+    want = np.array([[bin(int.from_bytes(bytes(x ^ y), "little")).count("1") for x in a] for y in b], np.uint16)
+    assert np.array_equal(mine, want)
+    ref = oracle.ref_hamming_matrix(a, b)
+    if ref is None:
+        pytest.skip("oracle/_ref/libhamming_ref.so not built (reference tree not mounted)")
+    assert np.array_equal(mine, ref)
+
+
+def test_median3_replicate_border(oracle):
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 65536, size=(6, 8)).astype(np.uint16)
+    got = oracle.median3(img)
+    pad = np.pad(img, 1, mode="edge")
+    want = np.empty_like(img)
+    for y in range(6):
+        for x in range(8):
+            want[y, x] = np.sort(pad[y:y + 3, x:x + 3].reshape(-1))[4]
+    assert np.array_equal(got, want)
+
+
+def test_float_path_matches_integer_path_on_integer_costs(oracle):
+    """With integer-valued float costs every float op is exact, so the float build
+    (sgm.h:129-157, sgm.cc:177-254) must reproduce the uint32 build's sums."""
+    rng = np.random.default_rng(11)
+    h, w, D = 9, 14, 8
+    Cu = rng.integers(0, 64, size=(h, w, D)).astype(np.uint8)
+    bu = np.zeros((h, w, D), np.uint32)
+    bf = np.zeros((h, w, D), np.float32)
+    Cf = Cu.astype(np.float32)
+    for dx, dy in oracle.directions(8):
+        oracle.aggregate_dir_u32(Cu, dx, dy, 3, 17, bu)
+        oracle.aggregate_dir_f32(Cf, dx, dy, 3, 17, bf)
+        assert np.array_equal(bu.astype(np.float32), bf)
