@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the census/Hamming SGM hot path on MI355X.
+
+One "step" = one pass of the whole hot path (census -> Hamming volume -> 8 ordered
+direction sweeps -> WTA/LR/subpixel -> median) over one batch of B synthetic KITTI-size
+stereo pairs per GPU, inputs and outputs resident in HBM.  Workload = BASELINE.json
+configs[1]: KITTI 1241x376, D=128, 8 paths, wsz=5, P1=3, P2=60.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: stereo pairs are independent, so every rank runs its own B pairs per step with
+no data-path collective (weak scaling); RCCL only carries the barrier and the max-over-ranks
+of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def box3(a):
+    """3x3 box blur with edge replication (vectorised; float32)."""
+    p = np.pad(a, 1, mode="edge")
+    return (p[:-2, :-2] + p[:-2, 1:-1] + p[:-2, 2:] + p[1:-1, :-2] + p[1:-1, 1:-1] + p[1:-1, 2:] +
+            p[2:, :-2] + p[2:, 1:-1] + p[2:, 2:]) / np.float32(9)
+
+
+def synthetic_pair(seed, H, W, max_disp):
+    """SURVEY.md 8d synthetic input: smooth random texture; the right view is the left
+    shifted by a piecewise-constant disparity field (row bands x column blocks) + N(0,2)."""
+    rng = np.random.default_rng(seed)
+    base = box3(rng.integers(0, 256, size=(H, W + max_disp)).astype(np.float32))
+    left = base[:, :W]
+    right = np.empty_like(left)
+    band = 24
+    for y0 in range(0, H, band):
+        d = int(rng.integers(0, max_disp))
+        right[y0:y0 + band] = base[y0:y0 + band, d:d + W]
+    right = right + rng.normal(0, 2.0, size=right.shape).astype(np.float32)
+    to8 = lambda a: np.ascontiguousarray(np.clip(a, 0, 255).astype(np.uint8))
+    return to8(left), to8(right)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="stereo pairs per GPU per step (one launch group)")
+    ap.add_argument("--width", type=int, default=1241)
+    ap.add_argument("--height", type=int, default=376)
+    ap.add_argument("--disp", type=int, default=128)
+    ap.add_argument("--wsz", type=int, default=5)
+    ap.add_argument("--p1", type=int, default=3)
+    ap.add_argument("--p2", type=int, default=60)
+    ap.add_argument("--paths", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the SGM engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import stereo_vision_amd as sv
+
+    W, H, D, B = args.width, args.height, args.disp, args.batch
+    eng = sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=args.wsz, penalty1=args.p1, penalty2=args.p2,
+                                          num_paths=args.paths, device=local_rank, max_batch=B))
+    # B distinct seeded pairs per rank; a handful of distinct textures is enough to keep the
+    # data realistic, so generate min(B, 8) and tile them
+    ndist = min(B, 8)
+    pairs = [synthetic_pair(1234 + rank * 1000 + i, H, W, 100) for i in range(ndist)]
+    Lh = np.stack([pairs[i % ndist][0] for i in range(B)])
+    Rh = np.stack([pairs[i % ndist][1] for i in range(B)])
+    dL = torch.from_numpy(Lh).cuda()
+    dR = torch.from_numpy(Rh).cuda()
+    dO = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.compute_device(dL.data_ptr(), dR.data_ptr(), dO.data_ptr(), B, W, H, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.kernel_stats()  # clear
+    eng.set_profiling(not args.no_events)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    stats = eng.kernel_stats()
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames = world * B * args.steps
+    fps = frames / dt
+    m = (args.wsz - 1) // 2
+    V = (W - 2 * m) * (H - 2 * m) * D
+    alg_total, alg_agg = eng.algorithmic_bytes(W, H)
+
+    out = {
+        "metric": "frames/s (KITTI 1241x376, D=128, 8-path census SGM)",
+        "value": round(fps, 2),
+        "unit": "frames/s",
+        "mde_per_s": round(fps * W * H * D / 1e6, 1),
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8 cost / u16 path cost",
+        "data": "synthetic",
+        "config": {"workload": "KITTI-size %dx%d census/Hamming SGM, D=%d, %d paths, wsz=%d, P1=%d, P2=%d" %
+                               (W, H, D, args.paths, args.wsz, args.p1, args.p2),
+                   "pairs_per_gpu_per_step": B, "sharding": "independent stereo pairs per rank, no data-path collective"},
+    }
+
+    if rank == 0:
+        # dominant kernel = the direction sweeps; algorithmic bytes of one launch (one direction
+        # over the launch group of B pairs) = B * V * (5N-2)/N on average over the N launches
+        agg_ms, agg_n = stats["aggregate"]
+        roof = None
+        if agg_n:
+            per_launch_bytes = B * alg_agg / args.paths
+            avg_s = agg_ms / agg_n * 1e-3
+            ach = per_launch_bytes / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": "aggregate_u16_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(agg_ms / agg_n, 4), "alg_bytes_per_launch": per_launch_bytes,
+                    "whole_pipeline_alg_GBs": round(alg_total * fps / world / 1e9, 1),
+                    "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stats.items()}}
+        out["roofline"] = roof
+
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            from oracle import oracle as o
+            o.build()
+            nfr = min(args.cpu_frames, ndist)
+            got = dO[:nfr].cpu().numpy().view(np.uint16)
+            t1 = time.perf_counter()
+            ok = True
+            for i in range(nfr):
+                want = o.sgm_census(pairs[i][0], pairs[i][1], D, args.wsz, args.p1, args.p2, args.paths)
+                ok = ok and bool(np.array_equal(want, got[i]))
+            cdt = time.perf_counter() - t1
+            cpu = {"value": round(nfr / cdt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "%d of the benchmark's own %dx%d D=%d frames through oracle/sgm_oracle.c (single thread, "
+                             "like the reference's aggregation)" % (nfr, W, H, D),
+                   "gpu_output_bit_exact_on_sample": ok}
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * sgmx.h -- C ABI of the MI355X-native semi-global matching engine (libsgmx.so).
+ *
+ * This is the drop-in boundary for the dense-stereo hot path of
+ * ivankreso/stereo-vision.  The reference has no FFI layer of its own: its seam
+ * is the C++ class API of reconstruction/base (recon::StereoSGM, recon::SGM).
+ * Every entry point below names the reference interface it replaces
+ * (file:line relative to the upstream tree).  include/sgmx_recon.hpp holds the
+ * C++ adapter classes with the reference's own signatures on top of this ABI;
+ * INTEGRATION.md shows how a maintainer binds it.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; all functions return an int status
+ *    (SGMX_OK == 0) and never throw or abort; sgmx_last_error() gives the text.
+ *  - "host" entry points take host pointers and are synchronous.
+ *  - "_dev" entry points take device pointers (hipMalloc'd memory on the
+ *    context's device) plus a hipStream_t passed as void*; they only enqueue
+ *    work on that stream and return; the caller synchronises.
+ *  - a context owns all device scratch and is reused across calls; one context
+ *    per (host thread, device).  Nothing is written to the file system.
+ *  - volumes are [y][x][d] with d fastest; images are row-major.
+ */
+#ifndef SGMX_H
+#define SGMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SGMX_API __attribute__((visibility("default")))
+#else
+#define SGMX_API
+#endif
+
+enum {
+    SGMX_OK = 0,
+    SGMX_ERR_INVALID_ARG = 1, /* null pointer, bad size, unsupported parameter */
+    SGMX_ERR_RANGE = 2,       /* penalties / disparity range outside the uint16 path-cost guarantee */
+    SGMX_ERR_NO_DEVICE = 3,   /* no usable HIP device (the engine has no CPU fallback) */
+    SGMX_ERR_HIP = 4,         /* a HIP runtime call failed; see sgmx_last_error */
+    SGMX_ERR_OOM = 5,
+    SGMX_ERR_STATE = 6        /* tap requested before a compute call, wrong context mode, ... */
+};
+
+/* Replaces struct StereoSGMParams (reconstruction/base/stereo_sgm.h:15-21) and
+ * struct SGMParams (reconstruction/base/sgm.h:18-23): the first four fields are
+ * theirs, same meaning.  The rest are extensions; zero selects the default. */
+typedef struct sgmx_params {
+    int disp_range;  /* number of disparities D, d in [0, D); 2 <= D <= 512                    */
+    int window_sz;   /* census window, odd, 1..31 (an even window reads past the image in the reference); m = (wsz-1)/2; ignored by the float path */
+    int penalty1;    /* P1 >= 0                                                                 */
+    int penalty2;    /* P2 >= 0; 36*255 + 8*P2 and P1 + 9*255 + P2 must stay below the uint16 guards */
+    int num_paths;   /* 8 (default; order of stereo_sgm.cc:120-122) or 4 (its axis-aligned subset) */
+    int device;      /* HIP device ordinal (default 0)                                           */
+    int max_batch;   /* stereo pairs processed per launch group (default 1); sizes the scratch   */
+    int flags;       /* reserved, must be 0                                                       */
+} sgmx_params;
+
+typedef struct sgmx_ctx sgmx_ctx;
+
+/* Library version string, e.g. "sgmx 0.1 (gfx950)". */
+SGMX_API const char *sgmx_version(void);
+
+/* Construct / destroy.  Replaces recon::StereoSGM::StereoSGM(StereoSGMParams&)
+ * (stereo_sgm.h:56) and recon::SGM::SGM(SGMParams&) (sgm.h:64).  Fails with
+ * SGMX_ERR_NO_DEVICE when no GPU is present -- there is no CPU path. */
+SGMX_API int sgmx_create(const sgmx_params *params, sgmx_ctx **out);
+SGMX_API void sgmx_destroy(sgmx_ctx *ctx);
+
+/* Text of the last error on this context (ctx may be NULL for create errors). */
+SGMX_API const char *sgmx_last_error(const sgmx_ctx *ctx);
+
+/* Census/Hamming SGM on one rectified 8-bit pair; replaces
+ * void recon::StereoSGM::compute(cv::Mat& left, cv::Mat& right, cv::Mat& disp)
+ * (stereo_sgm.h:57, stereo_sgm.cc:15-188, COST_CENSUS build).  left/right: H rows
+ * of W bytes, row pitch stride_* bytes.  disp: H rows of W uint16 (value = 256 *
+ * disparity, 0 = invalid, zero border of width m), row pitch stride_disp BYTES.
+ * The reference allocates disp itself (stereo_sgm.h:280); here the caller does. */
+SGMX_API int sgmx_compute_census_u8(sgmx_ctx *ctx, const uint8_t *left, const uint8_t *right, int W, int H,
+                                    int stride_left, int stride_right, uint16_t *disp, int stride_disp);
+
+/* The same for n pairs stored back to back (pair i at left + i*H*W etc., dense
+ * rows); what a driver such as scripts/run_sgm_batch_census.py:27-34 gets by
+ * looping over files, in one call.  Processes max_batch pairs per launch group. */
+SGMX_API int sgmx_compute_census_u8_batch(sgmx_ctx *ctx, int n, const uint8_t *left, const uint8_t *right, int W, int H,
+                                          uint16_t *disp);
+
+/* Device-resident form of the batch call: inputs and outputs already in HBM
+ * (dense), work enqueued on `stream`.  n may exceed max_batch. */
+SGMX_API int sgmx_compute_census_u8_dev(sgmx_ctx *ctx, int n, const uint8_t *d_left, const uint8_t *d_right, int W,
+                                        int H, uint16_t *d_disp, void *stream);
+
+/* Float data-cost SGM; replaces the part of
+ * cv::Mat recon::SGM::Compute(const std::string, const std::string) (sgm.h:65,
+ * sgm.cc:14-174) that follows the data-cost loop: `cost` is the [H][W][D] float
+ * volume the reference builds at sgm.cc:76-84 (FLT_MAX where x < d, sgm.cc:55),
+ * D == params.disp_range.  disp: H x W uint16, NO padding (sgm.h:291), dense. */
+SGMX_API int sgmx_compute_cost_f32(sgmx_ctx *ctx, const float *cost, int W, int H, int D, uint16_t *disp);
+SGMX_API int sgmx_compute_cost_f32_dev(sgmx_ctx *ctx, int n, const float *d_cost, int W, int H, int D,
+                                       uint16_t *d_disp, void *stream);
+
+/* ---- stage taps (host pointers; for parity tests and debugging) ---- */
+
+/* StereoCosts::census_transform (stereo_costs.cc:36-61): out is (H-2m) x (W-2m) uint32. */
+SGMX_API int sgmx_census_u32(sgmx_ctx *ctx, const uint8_t *img, int W, int H, int stride, uint32_t *out);
+
+/* The data-cost loop stereo_sgm.cc:75-101 with hamming_dist (stereo_costs.h:120-132)
+ * and the 255 initialisation (stereo_sgm.cc:43): census maps are h x w uint32,
+ * out is [h][w][D] uint8, D == params.disp_range. */
+SGMX_API int sgmx_hamming_volume_u8(sgmx_ctx *ctx, const uint32_t *census_left, const uint32_t *census_right, int w,
+                                    int h, uint8_t *out);
+
+/* compute_hamming (core/hamming.h:67-68, core/hamming.c:215-236):
+ * dis[j*na + i] = popcount(a_i xor b_j) over ncodes bytes. */
+SGMX_API int sgmx_hamming_matrix_u16(sgmx_ctx *ctx, uint16_t *dis, const uint8_t *a, const uint8_t *b, int na, int nb,
+                                     int ncodes);
+
+/* After a compute call, copy stages of pair `index` (0-based within the last
+ * launch group) to the host: the data cost C [h][w][D] (uint8 for the census
+ * path -- costs at stereo_sgm.cc:31-51; float for the float path), the summed
+ * path costs S [h][w][D] (aggr_costs, stereo_sgm.cc:133 / sgm.cc:116; uint16 here,
+ * uint32 in the reference, same values), the disparity image before the median
+ * (get_disparity_image_uint16, stereo_sgm.h:275-317 / sgm.h:285-332).  Any
+ * pointer may be NULL. */
+SGMX_API int sgmx_get_stages_census(sgmx_ctx *ctx, int index, uint8_t *C, uint16_t *S, uint16_t *raw_disp);
+SGMX_API int sgmx_get_stages_f32(sgmx_ctx *ctx, int index, float *S, uint16_t *raw_disp);
+
+/* GetDisparityImage (stereo_sgm.h:243-257): WTA on the raw data cost of pair
+ * `index` of the last census launch group, (h+2m) x (w+2m) uint8.  The reference
+ * writes this to ./data_cost_img.png on every call (stereo_sgm.cc:184-185); here
+ * it is computed only on request and never written to disk. */
+SGMX_API int sgmx_get_data_cost_wta_u8(sgmx_ctx *ctx, int index, uint8_t *out);
+
+/* ---- measurement ---- */
+
+enum {
+    SGMX_K_CENSUS = 0,
+    SGMX_K_HAMMING = 1,
+    SGMX_K_AGGREGATE = 2, /* all directions; one launch per direction per launch group */
+    SGMX_K_WTA = 3,
+    SGMX_K_MEDIAN = 4,
+    SGMX_K_COUNT = 5
+};
+
+/* When enabled every kernel launch is bracketed by HIP events on the launch
+ * stream; sgmx_kernel_stats synchronises, returns the accumulated duration and
+ * launch count of one kernel class and clears them. */
+SGMX_API int sgmx_set_profiling(sgmx_ctx *ctx, int enabled);
+SGMX_API int sgmx_kernel_stats(sgmx_ctx *ctx, int kernel_class, double *total_ms, long *launches);
+
+/* Algorithmic HBM bytes of one pair on the census path, B = V*(5N+1) + 10*W*H
+ * (SURVEY.md 8d), and of its aggregation launches alone, 5*N*V - 2*V. */
+SGMX_API double sgmx_algorithmic_bytes_census(const sgmx_ctx *ctx, int W, int H, double *aggregate_only);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGMX_H */

@@ -73,6 +73,8 @@ def directions(num_paths):
 def census(img, wsz):
     img = np.ascontiguousarray(img, np.uint8)
     H, W = img.shape
+    if wsz < 1 or wsz % 2 == 0:
+        raise ValueError("census window must be odd")
     m = (wsz - 1) // 2
     out = np.empty((H - 2 * m, W - 2 * m), np.uint32)
     lib().oracle_census_u32(img, W, H, W, wsz, out)

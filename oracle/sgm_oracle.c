@@ -35,7 +35,9 @@
 /* stereo_costs.cc:36-61 census_transform: window rows y..y+wsz-1 and columns
  * x..x+wsz-1 of the uncropped image, centre (y+m, x+m) skipped, row-major,
  * code = (code << 1) + (I(q) > I(c)) in a uint32 that silently drops high
- * bits for windows with more than 33 taps. Output is (H-2m) x (W-2m). */
+ * bits for windows with more than 33 taps. Output is (H-2m) x (W-2m).  wsz must
+ * be odd: with an even window the reference's own loop reads one row and one
+ * column past the image (undefined behaviour), so that case is not restated. */
 ORACLE_API void oracle_census_u32(const uint8_t *img, int W, int H, int stride, int wsz, uint32_t *out)
 {
     const int m = (wsz - 1) / 2;
@@ -357,7 +359,7 @@ ORACLE_API int oracle_sgm_census(const uint8_t *left, const uint8_t *right, int 
 {
     const int m = (wsz - 1) / 2;
     const int w = W - 2 * m, h = H - 2 * m;
-    if (w <= 0 || h <= 0 || D < 1 || (num_paths != 4 && num_paths != 8))
+    if (w <= 0 || h <= 0 || D < 1 || (num_paths != 4 && num_paths != 8) || wsz < 1 || (wsz & 1) == 0)
         return -1;
     const size_t npix = (size_t)w * h, nvox = npix * D;
     uint32_t *cl = malloc(npix * 4), *cr = malloc(npix * 4);

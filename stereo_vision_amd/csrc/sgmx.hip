@@ -1,0 +1,724 @@
+// sgmx.hip -- context management and the C ABI (include/sgmx.h) of the SGM engine.
+// HIP only: there is no CPU fallback anywhere in this library; sgmx_create fails
+// with SGMX_ERR_NO_DEVICE when no GPU is usable.
+#include "../../include/sgmx.h"
+#include "sgmx_kernels.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace sgmx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const int DIRS8[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}}; // stereo_sgm.cc:120-122
+const int DIRS4[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
+
+struct ProfRec {
+    int cls;
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct sgmx_ctx {
+    sgmx_params prm;
+    int R = 1;  // packed uint16 pairs per lane (census) / float pairs per lane (float path)
+    int Dp = 128;
+    std::string err;
+
+    // geometry the scratch is currently sized for
+    int W = 0, H = 0;          // census: full image; float: volume size
+    int w = 0, h = 0, m = 0;   // cropped
+    int mode = 0;              // 0 none, 1 census, 2 float
+    int last_n = 0;            // pairs in the last launch group
+
+    // device scratch (sized for max_batch pairs)
+    uint8_t *d_left = nullptr, *d_right = nullptr; // staged inputs for the host entry points
+    u32 *d_cl = nullptr, *d_cr = nullptr;
+    void *d_C = nullptr;   // uint8 or float, pitch Dp
+    void *d_S = nullptr;   // uint16 or float, pitch Dp
+    void *d_BL = nullptr;  // border ring
+    uint16_t *d_raw = nullptr, *d_out = nullptr;
+    size_t bytes_C = 0, bytes_S = 0, bytes_BL = 0;
+
+    hipStream_t own_stream = nullptr;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    double prof_ms[SGMX_K_COUNT] = {0};
+    long prof_n[SGMX_K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(sgmx_ctx *c, int code, const std::string &msg)
+{
+    if (c)
+        c->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                                \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return fail((c), e_ == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP,                                  \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                            \
+    } while (0)
+
+void free_scratch(sgmx_ctx *c)
+{
+    void *ptrs[] = {c->d_left, c->d_right, c->d_cl, c->d_cr, c->d_C, c->d_S, c->d_BL, c->d_raw, c->d_out};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    c->d_left = c->d_right = nullptr;
+    c->d_cl = c->d_cr = nullptr;
+    c->d_C = c->d_S = c->d_BL = nullptr;
+    c->d_raw = c->d_out = nullptr;
+    c->mode = 0;
+    c->W = c->H = 0;
+}
+
+// (Re)allocate scratch for `mode` at image/volume size W x H.
+int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
+{
+    if (c->mode == mode && c->W == W && c->H == H)
+        return SGMX_OK;
+    free_scratch(c);
+    const int B = c->prm.max_batch;
+    const int m = mode == 1 ? (c->prm.window_sz - 1) / 2 : 0;
+    const int w = W - 2 * m, h = H - 2 * m;
+    const size_t npix = (size_t)w * h, nfull = (size_t)W * H;
+    const size_t esz_c = mode == 1 ? 1 : 4, esz_s = mode == 1 ? 2 : 4;
+    c->bytes_C = npix * c->Dp * esz_c;
+    c->bytes_S = npix * c->Dp * esz_s;
+    c->bytes_BL = (size_t)(2 * w + 2 * h) * c->Dp * esz_s;
+    if (mode == 1) {
+        HIPCHK(c, hipMalloc((void **)&c->d_left, nfull * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_right, nfull * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_cl, npix * 4 * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_cr, npix * 4 * B));
+    }
+    HIPCHK(c, hipMalloc(&c->d_C, c->bytes_C * B));
+    HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * B));
+    HIPCHK(c, hipMalloc(&c->d_BL, c->bytes_BL * B));
+    HIPCHK(c, hipMalloc((void **)&c->d_raw, nfull * 2 * B));
+    HIPCHK(c, hipMalloc((void **)&c->d_out, nfull * 2 * B));
+    // the zero border of the disparity image (stereo_sgm.h:280) is written once here;
+    // the WTA kernel only ever touches the interior
+    HIPCHK(c, hipMemset(c->d_raw, 0, nfull * 2 * B));
+    c->mode = mode;
+    c->W = W;
+    c->H = H;
+    c->w = w;
+    c->h = h;
+    c->m = m;
+    return SGMX_OK;
+}
+
+struct ProfScope {
+    sgmx_ctx *c;
+    hipStream_t st;
+    ProfRec r;
+    bool on;
+    ProfScope(sgmx_ctx *c_, int cls, hipStream_t s) : c(c_), st(s), on(c_->profiling)
+    {
+        if (on) {
+            r.cls = cls;
+            on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess;
+            if (on)
+                (void)hipEventRecord(r.a, st);
+        }
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            (void)hipEventRecord(r.b, st);
+            c->prof.push_back(r);
+        }
+    }
+};
+
+template <int R, bool FIRST, bool HAS_PAD>
+void launch_agg_u16(const AggArgs &a, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((aggregate_u16_kernel<R, FIRST, HAS_PAD, (R == 4 ? 4 : 8)>), grid, dim3(256), 0, st, a);
+}
+template <int R, bool FIRST, bool HAS_PAD>
+void launch_agg_f32(const AggArgs &a, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((aggregate_f32_kernel<R, FIRST, HAS_PAD, (R == 4 ? 2 : (R == 2 ? 4 : 8))>), grid, dim3(256), 0,
+                       st, a);
+}
+
+template <bool F32> void launch_agg(int R, bool first, bool pad, const AggArgs &a, dim3 grid, hipStream_t st)
+{
+#define SGMX_DISPATCH(RR)                                                                                              \
+    if (first) {                                                                                                       \
+        if (pad)                                                                                                       \
+            F32 ? launch_agg_f32<RR, true, true>(a, grid, st) : launch_agg_u16<RR, true, true>(a, grid, st);            \
+        else                                                                                                           \
+            F32 ? launch_agg_f32<RR, true, false>(a, grid, st) : launch_agg_u16<RR, true, false>(a, grid, st);          \
+    } else {                                                                                                           \
+        if (pad)                                                                                                       \
+            F32 ? launch_agg_f32<RR, false, true>(a, grid, st) : launch_agg_u16<RR, false, true>(a, grid, st);          \
+        else                                                                                                           \
+            F32 ? launch_agg_f32<RR, false, false>(a, grid, st) : launch_agg_u16<RR, false, false>(a, grid, st);        \
+    }
+    if (R == 1) {
+        SGMX_DISPATCH(1)
+    } else if (R == 2) {
+        SGMX_DISPATCH(2)
+    } else {
+        SGMX_DISPATCH(4)
+    }
+#undef SGMX_DISPATCH
+}
+
+// The 8 (or 4) ordered direction sweeps over n pairs resident in c->d_C.
+int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st)
+{
+    const int np = c->prm.num_paths;
+    HIPCHK(c, hipMemsetAsync(c->d_BL, 0, c->bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
+    for (int k = 0; k < np; k++) {
+        AggArgs a;
+        a.C = c->d_C;
+        a.S = c->d_S;
+        a.BL = c->d_BL;
+        a.w = c->w;
+        a.h = c->h;
+        a.D = c->prm.disp_range;
+        a.dx = np == 8 ? DIRS8[k][0] : DIRS4[k][0];
+        a.dy = np == 8 ? DIRS8[k][1] : DIRS4[k][1];
+        a.P1 = c->prm.penalty1;
+        a.P2 = c->prm.penalty2;
+        a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
+        a.first = k == 0;
+        const dim3 grid((a.npaths + 3) / 4, n);
+        ProfScope ps(c, SGMX_K_AGGREGATE, st);
+        if (f32)
+            launch_agg<true>(c->R, k == 0, c->prm.disp_range != c->Dp, a, grid, st);
+        else
+            launch_agg<false>(c->R, k == 0, c->prm.disp_range != c->Dp, a, grid, st);
+        HIPCHK(c, hipGetLastError());
+    }
+    return SGMX_OK;
+}
+
+int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t st)
+{
+    const int W = c->W, H = c->H;
+    {
+        ProfScope ps(c, SGMX_K_WTA, st);
+        const dim3 grid(c->h, n);
+        if (!f32) {
+            const size_t lds = (size_t)c->w * 8;
+            if (c->R == 1)
+                hipLaunchKernelGGL(wta_u16_kernel<1>, grid, dim3(256), lds, st, (const uint16_t *)c->d_S, c->w, c->h, c->prm.disp_range, c->m, c->d_raw);
+            else if (c->R == 2)
+                hipLaunchKernelGGL(wta_u16_kernel<2>, grid, dim3(256), lds, st, (const uint16_t *)c->d_S, c->w, c->h, c->prm.disp_range, c->m, c->d_raw);
+            else
+                hipLaunchKernelGGL(wta_u16_kernel<4>, grid, dim3(256), lds, st, (const uint16_t *)c->d_S, c->w, c->h, c->prm.disp_range, c->m, c->d_raw);
+        } else {
+            const size_t lds = (size_t)c->w * 16;
+            if (c->R == 1)
+                hipLaunchKernelGGL(wta_f32_kernel<1>, grid, dim3(256), lds, st, (const float *)c->d_S, c->w, c->h, c->prm.disp_range, c->d_raw);
+            else if (c->R == 2)
+                hipLaunchKernelGGL(wta_f32_kernel<2>, grid, dim3(256), lds, st, (const float *)c->d_S, c->w, c->h, c->prm.disp_range, c->d_raw);
+            else
+                hipLaunchKernelGGL(wta_f32_kernel<4>, grid, dim3(256), lds, st, (const float *)c->d_S, c->w, c->h, c->prm.disp_range, c->d_raw);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, SGMX_K_MEDIAN, st);
+        hipLaunchKernelGGL(median3_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, st, c->d_raw, W, H, d_disp);
+        HIPCHK(c, hipGetLastError());
+    }
+    return SGMX_OK;
+}
+
+// One launch group (n <= max_batch) of the census path, everything device resident.
+int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint16_t *d_disp, hipStream_t st)
+{
+    const int W = c->W, H = c->H, w = c->w, h = c->h;
+    {
+        ProfScope ps(c, SGMX_K_CENSUS, st);
+        hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 2 * n), dim3(256), 0, st, dL, dR, n, W, H,
+                           c->prm.window_sz, c->d_cl, c->d_cr);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, SGMX_K_HAMMING, st);
+        const size_t groups = (size_t)n * w * h * (c->Dp / 16);
+        hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, c->d_cl,
+                           c->d_cr, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
+        HIPCHK(c, hipGetLastError());
+    }
+    int rc = run_aggregation(c, n, false, st);
+    if (rc)
+        return rc;
+    rc = run_wta_median(c, n, false, d_disp, st);
+    c->last_n = n;
+    return rc;
+}
+
+int check_size(sgmx_ctx *c, int W, int H, bool census)
+{
+    if (!c)
+        return SGMX_ERR_INVALID_ARG;
+    const int m = census ? (c->prm.window_sz - 1) / 2 : 0;
+    if (W - 2 * m < 1 || H - 2 * m < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "image smaller than the census window");
+    if ((size_t)(W - 2 * m) * (H - 2 * m) * c->Dp >= (size_t)1 << 31)
+        return fail(c, SGMX_ERR_INVALID_ARG, "cost volume of one pair exceeds 2^31 voxels");
+    return SGMX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *sgmx_version(void) { return "sgmx 0.1 (gfx950, HIP)"; }
+
+const char *sgmx_last_error(const sgmx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
+{
+    if (!params || !out)
+        return fail(nullptr, SGMX_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    sgmx_params p = *params;
+    if (p.num_paths == 0)
+        p.num_paths = 8;
+    if (p.max_batch == 0)
+        p.max_batch = 1;
+    if (p.window_sz == 0)
+        p.window_sz = 1;
+    if (p.disp_range < 2 || p.disp_range > 512)
+        return fail(nullptr, SGMX_ERR_INVALID_ARG, "disp_range must be in [2, 512]");
+    if (p.window_sz < 1 || p.window_sz > 31 || (p.window_sz & 1) == 0)
+        return fail(nullptr, SGMX_ERR_INVALID_ARG, "window_sz must be odd and in [1, 31]");
+    if (p.num_paths != 4 && p.num_paths != 8)
+        return fail(nullptr, SGMX_ERR_INVALID_ARG, "num_paths must be 4 or 8");
+    if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 || p.flags != 0)
+        return fail(nullptr, SGMX_ERR_INVALID_ARG, "negative penalty, bad max_batch or non-zero flags");
+    // uint16 guarantees: L_k <= 255*(k+1) + P2 on any pixel, so S <= 36*255 + 8*P2, and the
+    // "no disparity" sentinel 0x7FFF must stay above every L + P1 (sgmx_kernels.hpp INF16).
+    if (36LL * 255 + 8LL * p.penalty2 > 65535 || 9LL * 255 + p.penalty2 + p.penalty1 >= 0x7FFF ||
+        0x7FFFLL + p.penalty1 > 65535)
+        return fail(nullptr, SGMX_ERR_RANGE, "penalties too large for uint16 path costs (need 9180 + 8*P2 <= 65535)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SGMX_ERR_NO_DEVICE, "no HIP device visible; sgmx has no CPU fallback");
+    if (p.device < 0 || p.device >= ndev)
+        return fail(nullptr, SGMX_ERR_INVALID_ARG, "device ordinal out of range");
+    sgmx_ctx *c = new (std::nothrow) sgmx_ctx();
+    if (!c)
+        return fail(nullptr, SGMX_ERR_OOM, "host allocation failed");
+    c->prm = p;
+    c->R = p.disp_range <= 128 ? 1 : (p.disp_range <= 256 ? 2 : 4);
+    c->Dp = 128 * c->R;
+    if (hipSetDevice(p.device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+        delete c;
+        return fail(nullptr, SGMX_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
+    }
+    *out = c;
+    return SGMX_OK;
+}
+
+void sgmx_destroy(sgmx_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->prm.device);
+    (void)hipDeviceSynchronize();
+    for (auto &r : ctx->prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    free_scratch(ctx);
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int sgmx_compute_census_u8_dev(sgmx_ctx *c, int n, const uint8_t *d_left, const uint8_t *d_right, int W, int H,
+                               uint16_t *d_disp, void *stream)
+{
+    if (!c || !d_left || !d_right || !d_disp || n < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or n < 1");
+    int rc = check_size(c, W, H, true);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    rc = ensure_scratch(c, 1, W, H);
+    if (rc)
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nfull = (size_t)W * H;
+    for (int i = 0; i < n; i += c->prm.max_batch) {
+        const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
+        rc = census_group(c, g, d_left + i * nfull, d_right + i * nfull, d_disp + i * nfull, st);
+        if (rc)
+            return rc;
+    }
+    return SGMX_OK;
+}
+
+int sgmx_compute_census_u8_batch(sgmx_ctx *c, int n, const uint8_t *left, const uint8_t *right, int W, int H,
+                                 uint16_t *disp)
+{
+    if (!c || !left || !right || !disp || n < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or n < 1");
+    int rc = check_size(c, W, H, true);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    rc = ensure_scratch(c, 1, W, H);
+    if (rc)
+        return rc;
+    hipStream_t st = c->own_stream;
+    const size_t nfull = (size_t)W * H;
+    for (int i = 0; i < n; i += c->prm.max_batch) {
+        const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
+        HIPCHK(c, hipMemcpyAsync(c->d_left, left + i * nfull, nfull * g, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_right, right + i * nfull, nfull * g, hipMemcpyHostToDevice, st));
+        rc = census_group(c, g, c->d_left, c->d_right, c->d_out, st);
+        if (rc)
+            return rc;
+        HIPCHK(c, hipMemcpyAsync(disp + i * nfull, c->d_out, nfull * 2 * g, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    return SGMX_OK;
+}
+
+int sgmx_compute_census_u8(sgmx_ctx *c, const uint8_t *left, const uint8_t *right, int W, int H, int stride_left,
+                           int stride_right, uint16_t *disp, int stride_disp)
+{
+    if (!c || !left || !right || !disp)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer");
+    if (stride_left < W || stride_right < W || stride_disp < 2 * W)
+        return fail(c, SGMX_ERR_INVALID_ARG, "row pitch smaller than the row");
+    int rc = check_size(c, W, H, true);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    rc = ensure_scratch(c, 1, W, H);
+    if (rc)
+        return rc;
+    hipStream_t st = c->own_stream;
+    HIPCHK(c, hipMemcpy2DAsync(c->d_left, W, left, stride_left, W, H, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpy2DAsync(c->d_right, W, right, stride_right, W, H, hipMemcpyHostToDevice, st));
+    rc = census_group(c, 1, c->d_left, c->d_right, c->d_out, st);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipMemcpy2DAsync(disp, stride_disp, c->d_out, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return SGMX_OK;
+}
+
+int sgmx_compute_cost_f32_dev(sgmx_ctx *c, int n, const float *d_cost, int W, int H, int D, uint16_t *d_disp,
+                              void *stream)
+{
+    if (!c || !d_cost || !d_disp || n < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or n < 1");
+    if (D != c->prm.disp_range)
+        return fail(c, SGMX_ERR_INVALID_ARG, "D differs from params.disp_range");
+    int rc = check_size(c, W, H, false);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    rc = ensure_scratch(c, 2, W, H);
+    if (rc)
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)W * H;
+    for (int i = 0; i < n; i += c->prm.max_batch) {
+        const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
+        const float *src = d_cost + (size_t)i * npix * D;
+        const void *saveC = c->d_C;
+        if (D == c->Dp) {
+            c->d_C = const_cast<float *>(src); // stream the caller's volume in place
+        } else {
+            const size_t tot = (size_t)g * npix * c->Dp;
+            hipLaunchKernelGGL(repitch_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, D,
+                               (float *)c->d_C, c->Dp, (size_t)g * npix, 0.f);
+        }
+        rc = run_aggregation(c, g, true, st);
+        c->d_C = const_cast<void *>(saveC);
+        if (rc)
+            return rc;
+        rc = run_wta_median(c, g, true, d_disp + i * npix, st);
+        if (rc)
+            return rc;
+        c->last_n = g;
+    }
+    return SGMX_OK;
+}
+
+int sgmx_compute_cost_f32(sgmx_ctx *c, const float *cost, int W, int H, int D, uint16_t *disp)
+{
+    if (!c || !cost || !disp)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer");
+    if (D != c->prm.disp_range)
+        return fail(c, SGMX_ERR_INVALID_ARG, "D differs from params.disp_range");
+    int rc = check_size(c, W, H, false);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    const size_t npix = (size_t)W * H;
+    float *d_in = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_in, npix * D * 4));
+    hipStream_t st = c->own_stream;
+    hipError_t e = hipMemcpyAsync(d_in, cost, npix * D * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = ensure_scratch(c, 2, W, H);
+        if (!rc)
+            rc = sgmx_compute_cost_f32_dev(c, 1, d_in, W, H, D, c->d_out, st);
+        if (!rc)
+            e = hipMemcpyAsync(disp, c->d_out, npix * 2, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_in);
+    if (rc)
+        return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("float path copy/sync: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_census_u32(sgmx_ctx *c, const uint8_t *img, int W, int H, int stride, uint32_t *out)
+{
+    if (!c || !img || !out || stride < W)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad pitch");
+    int rc = check_size(c, W, H, true);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    const int m = (c->prm.window_sz - 1) / 2, w = W - 2 * m, h = H - 2 * m;
+    uint8_t *d_img = nullptr;
+    u32 *d_o = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_img, (size_t)W * H));
+    if (hipMalloc((void **)&d_o, (size_t)w * h * 4 * 2) != hipSuccess) {
+        (void)hipFree(d_img);
+        return fail(c, SGMX_ERR_OOM, "hipMalloc failed");
+    }
+    hipStream_t st = c->own_stream;
+    hipError_t e = hipMemcpy2DAsync(d_img, W, img, stride, W, H, hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 1), dim3(256), 0, st, d_img, d_img, 1, W, H,
+                       c->prm.window_sz, d_o, d_o + (size_t)w * h);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, d_o, (size_t)w * h * 4, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_img);
+    (void)hipFree(d_o);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("census tap: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_hamming_volume_u8(sgmx_ctx *c, const uint32_t *cl, const uint32_t *cr, int w, int h, uint8_t *out)
+{
+    if (!c || !cl || !cr || !out || w < 1 || h < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    const int D = c->prm.disp_range, Dp = c->Dp;
+    const size_t npix = (size_t)w * h;
+    u32 *d_c = nullptr;
+    uint8_t *d_v = nullptr, *d_o = nullptr;
+    hipError_t e = hipMalloc((void **)&d_c, npix * 8);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_v, npix * Dp);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_o, npix * D);
+    hipStream_t st = c->own_stream;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_c, cl, npix * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_c + npix, cr, npix * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const size_t groups = npix * (Dp / 16);
+        hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, d_c,
+                           d_c + npix, w, h, D, Dp, d_v, groups);
+        const size_t tot = npix * D;
+        hipLaunchKernelGGL(repitch_kernel<uint8_t>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_v, Dp, d_o,
+                           D, npix, (uint8_t)0);
+        e = hipMemcpyAsync(out, d_o, tot, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_c);
+    (void)hipFree(d_v);
+    (void)hipFree(d_o);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("hamming tap: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_hamming_matrix_u16(sgmx_ctx *c, uint16_t *dis, const uint8_t *a, const uint8_t *b, int na, int nb, int ncodes)
+{
+    if (!c || !dis || !a || !b || na < 1 || nb < 1 || ncodes < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    uint8_t *d_a = nullptr, *d_b = nullptr;
+    uint16_t *d_d = nullptr;
+    hipError_t e = hipMalloc((void **)&d_a, (size_t)na * ncodes + 4);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_b, (size_t)nb * ncodes + 4);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_d, (size_t)na * nb * 2);
+    hipStream_t st = c->own_stream;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_a, a, (size_t)na * ncodes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_b, b, (size_t)nb * ncodes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hamming_matrix_kernel, dim3((na + 255) / 256, nb), dim3(256), 0, st, d_d, d_a, d_b, na, nb,
+                           ncodes);
+        e = hipMemcpyAsync(dis, d_d, (size_t)na * nb * 2, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_a);
+    (void)hipFree(d_b);
+    (void)hipFree(d_d);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("hamming matrix: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16_t *raw)
+{
+    if (!c)
+        return SGMX_ERR_INVALID_ARG;
+    if (c->mode != mode || c->last_n < 1)
+        return fail(c, SGMX_ERR_STATE, "no matching compute call precedes this tap");
+    if (index < 0 || index >= c->last_n)
+        return fail(c, SGMX_ERR_INVALID_ARG, "pair index outside the last launch group");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    HIPCHK(c, hipDeviceSynchronize());
+    const int D = c->prm.disp_range, Dp = c->Dp;
+    const size_t npix = (size_t)c->w * c->h, tot = npix * D;
+    const size_t esz_c = mode == 1 ? 1 : 4, esz_s = mode == 1 ? 2 : 4;
+    void *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, tot * 4));
+    hipStream_t st = c->own_stream;
+    hipError_t e = hipSuccess;
+    const unsigned nb = (unsigned)((tot + 255) / 256);
+    if (C && mode == 1) {
+        hipLaunchKernelGGL(repitch_kernel<uint8_t>, dim3(nb), dim3(256), 0, st,
+                           (const uint8_t *)c->d_C + index * c->bytes_C, Dp, (uint8_t *)tmp, D, npix, (uint8_t)0);
+        e = hipMemcpyAsync(C, tmp, tot * esz_c, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+    }
+    if (S && e == hipSuccess) {
+        if (mode == 1)
+            hipLaunchKernelGGL(repitch_kernel<uint16_t>, dim3(nb), dim3(256), 0, st,
+                               (const uint16_t *)((const uint8_t *)c->d_S + index * c->bytes_S), Dp, (uint16_t *)tmp, D,
+                               npix, (uint16_t)0);
+        else
+            hipLaunchKernelGGL(repitch_kernel<float>, dim3(nb), dim3(256), 0, st,
+                               (const float *)((const uint8_t *)c->d_S + index * c->bytes_S), Dp, (float *)tmp, D, npix,
+                               0.f);
+        e = hipMemcpyAsync(S, tmp, tot * esz_s, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+    }
+    if (raw && e == hipSuccess)
+        e = hipMemcpy(raw, c->d_raw + (size_t)index * c->W * c->H, (size_t)c->W * c->H * 2, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("stage tap: ") + hipGetErrorString(e));
+    return SGMX_OK;
+}
+
+int sgmx_get_stages_census(sgmx_ctx *c, int index, uint8_t *C, uint16_t *S, uint16_t *raw_disp)
+{
+    return get_stages(c, 1, index, C, S, raw_disp);
+}
+
+int sgmx_get_stages_f32(sgmx_ctx *c, int index, float *S, uint16_t *raw_disp)
+{
+    return get_stages(c, 2, index, nullptr, S, raw_disp);
+}
+
+int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
+{
+    if (!c || !out)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer");
+    if (c->mode != 1 || c->last_n < 1)
+        return fail(c, SGMX_ERR_STATE, "no census compute call precedes this tap");
+    if (index < 0 || index >= c->last_n)
+        return fail(c, SGMX_ERR_INVALID_ARG, "pair index outside the last launch group");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    HIPCHK(c, hipDeviceSynchronize());
+    uint8_t *d_o = nullptr;
+    const size_t nfull = (size_t)c->W * c->H;
+    HIPCHK(c, hipMalloc((void **)&d_o, nfull));
+    hipStream_t st = c->own_stream;
+    hipError_t e = hipMemsetAsync(d_o, 0, nfull, st);
+    hipLaunchKernelGGL(data_cost_wta_kernel, dim3((c->w + 255) / 256, c->h), dim3(256), 0, st,
+                       (const uint8_t *)c->d_C + index * c->bytes_C, c->w, c->h, c->prm.disp_range, c->Dp, c->m, d_o);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, d_o, nfull, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_o);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("data-cost WTA tap: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_set_profiling(sgmx_ctx *c, int enabled)
+{
+    if (!c)
+        return SGMX_ERR_INVALID_ARG;
+    c->profiling = enabled != 0;
+    return SGMX_OK;
+}
+
+int sgmx_kernel_stats(sgmx_ctx *c, int cls, double *total_ms, long *launches)
+{
+    if (!c || cls < 0 || cls >= SGMX_K_COUNT)
+        return fail(c, SGMX_ERR_INVALID_ARG, "bad kernel class");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    HIPCHK(c, hipDeviceSynchronize());
+    for (auto &r : c->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->prof_ms[r.cls] += ms;
+            c->prof_n[r.cls] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    c->prof.clear();
+    if (total_ms)
+        *total_ms = c->prof_ms[cls];
+    if (launches)
+        *launches = c->prof_n[cls];
+    c->prof_ms[cls] = 0;
+    c->prof_n[cls] = 0;
+    return SGMX_OK;
+}
+
+double sgmx_algorithmic_bytes_census(const sgmx_ctx *c, int W, int H, double *aggregate_only)
+{
+    if (!c)
+        return 0.0;
+    const int m = (c->prm.window_sz - 1) / 2;
+    const double V = (double)(W - 2 * m) * (H - 2 * m) * c->prm.disp_range;
+    const int N = c->prm.num_paths;
+    if (aggregate_only)
+        *aggregate_only = V * (5.0 * N - 2.0); // N reads of C, S written once then N-1 read-modify-writes
+    return V * (5.0 * N + 1.0) + 10.0 * W * H;
+}
+
+} // extern "C"

@@ -1,0 +1,740 @@
+// sgmx_kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the SGM engine.
+//
+// Data layout in HBM (per stereo pair, pairs of a launch group back to back):
+//   census  uint32 [h][w]                         (stereo_costs.cc:36-61)
+//   C       uint8  [h][w][Dp]   Dp = 128*R >= D   (stereo_sgm.cc:75-101; pad d >= D holds 0)
+//   S       uint16 [h][w][Dp]   summed path costs (aggr_costs, stereo_sgm.cc:133)
+//   BL      uint16 [2w+2h][Dp]  path costs L_k of the image-border pixels only
+//   raw/out uint16 [H][W]
+// The reference keeps a full path-cost volume that it never clears between
+// directions (stereo_sgm.cc:46, :142): direction k starts from L_{k-1}(p) + C(p)
+// on its start pixels.  Start pixels are always border pixels, so carrying the
+// border ring BL from direction to direction reproduces that exactly without a
+// [h][w][D] path-cost volume in memory.
+//
+// Aggregation mapping: one wavefront per path (scanline / column / diagonal),
+// the disparity axis across the 64 lanes, 2R disparities per lane as R packed
+// uint16 pairs held in registers; neighbours d+-1 come from DPP wave shifts,
+// min_k from a DPP row reduction; the cost volume is streamed with loads issued
+// PF steps ahead of their use.  No LDS, no MFMA (the path is a min-plus
+// recurrence, not a contraction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sgmx {
+
+typedef uint32_t u32;
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// "no such disparity": larger than any reachable path cost, and INF + P1 still
+// fits uint16 (the host validates the penalties against these guards).
+constexpr u32 INF16 = 0x7FFFu;
+constexpr u32 INF2 = 0x7FFF7FFFu;
+
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return __builtin_bit_cast(u32, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b))); }
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { return __builtin_bit_cast(u32, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b))); }
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
+
+// DPP controls (gfx9 family): row_shr:n = 0x110+n, wave_shl:1 = 0x130, wave_shr:1 = 0x138,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ u32 dpp(u32 old, u32 src)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false);
+}
+
+// Minimum of a 32-bit value over the 64 lanes, returned wave-uniform (SGPR).
+// `old` = UINT_MAX is the identity of umin, which lets the compiler fold each DPP
+// move into a single v_min_u32_dpp (lanes without a source keep their value).
+__device__ __forceinline__ u32 wave_min_u32(u32 x)
+{
+    x = min(x, dpp<0x111>(0xFFFFFFFFu, x));          // row_shr:1
+    x = min(x, dpp<0x112>(0xFFFFFFFFu, x));          // row_shr:2
+    x = min(x, dpp<0x114>(0xFFFFFFFFu, x));          // row_shr:4
+    x = min(x, dpp<0x118>(0xFFFFFFFFu, x));          // row_shr:8  -> lane 15 of each row
+    x = min(x, dpp<0x142, 0xA>(0xFFFFFFFFu, x));     // row_bcast:15 -> lanes 31, 63
+    x = min(x, dpp<0x143, 0xC>(0xFFFFFFFFu, x));     // row_bcast:31 -> lane 63
+    return (u32)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// float <-> uint32 whose unsigned order is the float order (-0 folded onto +0)
+__device__ __forceinline__ u32 float_key(float f)
+{
+    const u32 b = __builtin_bit_cast(u32, f + 0.0f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(u32 k)
+{
+    return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__device__ __forceinline__ float wave_min_f32(float x) { return key_float(wave_min_u32(float_key(x))); }
+
+// ---------------------------------------------------------------------------
+// K1 census transform.  One thread per cropped pixel; z = image index (n left
+// images then n right images).  stereo_costs.cc:36-61.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void census_kernel(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
+                                                     int n, int W, int H, int wsz, u32 *__restrict__ cens_left,
+                                                     u32 *__restrict__ cens_right)
+{
+    const int m = (wsz - 1) / 2;
+    const int w = W - 2 * m, h = H - 2 * m;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int z = blockIdx.z;
+    if (x >= w || y >= h)
+        return;
+    const uint8_t *img = (z < n ? left + (size_t)z * W * H : right + (size_t)(z - n) * W * H);
+    u32 *out = (z < n ? cens_left + (size_t)z * w * h : cens_right + (size_t)(z - n) * w * h);
+    const int cy = y + m, cx = x + m;
+    const uint8_t c = img[(size_t)cy * W + cx];
+    u32 code = 0;
+    for (int py = y; py < y + wsz; py++) {
+        const uint8_t *row = img + (size_t)py * W;
+        for (int px = x; px < x + wsz; px++) {
+            if (px == cx && py == cy)
+                continue;
+            code = (code << 1) + (row[px] > c ? 1u : 0u);
+        }
+    }
+    out[(size_t)y * w + x] = code;
+}
+
+// ---------------------------------------------------------------------------
+// K2 Hamming data-cost volume.  One thread per (pixel, group of 16 disparities),
+// one 16-byte store each, disparity groups fastest so a wave writes whole lines.
+// stereo_sgm.cc:43,75-101 + stereo_costs.h:120-132.  Pad disparities d >= D get 0.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hamming_volume_kernel(const u32 *__restrict__ cens_left,
+                                                             const u32 *__restrict__ cens_right, int w, int h, int D,
+                                                             int Dp, uint8_t *__restrict__ C, size_t total_groups)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_groups)
+        return;
+    const int gpp = Dp >> 4; // groups per pixel
+    const size_t pix = t / gpp; // pixel index over all pairs of the launch group
+    const int g = (int)(t - pix * gpp);
+    const int x = (int)(pix % (size_t)w);
+    const u32 cl = cens_left[pix];
+    const u32 *cr = cens_right + pix;
+    u32 o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        u32 v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int d = g * 16 + q * 4 + b;
+            u32 c;
+            if (d >= D)
+                c = 0u;
+            else if (d > x)
+                c = 255u;
+            else
+                c = (u32)__builtin_popcount(cl ^ cr[-d]);
+            v |= c << (8 * b);
+        }
+        o[q] = v;
+    }
+    *reinterpret_cast<uint4 *>(C + pix * (size_t)Dp + (size_t)g * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ---------------------------------------------------------------------------
+// K3 path aggregation, census build (uint8 C, uint16 L and S).
+// stereo_sgm.cc:191-268 (sweep), stereo_sgm.h:119-147 (recurrence), :85-117 (sum).
+// ---------------------------------------------------------------------------
+struct AggArgs {
+    const void *C;    // data cost, [pairs][h][w][Dp]
+    void *S;          // summed path cost, same shape
+    void *BL;         // border ring, [pairs][2w+2h][Dp]
+    int w, h, D;      // cropped size, real disparity count
+    int dx, dy;       // direction; predecessor of (y,x) is (y-dy, x-dx)
+    int P1, P2;
+    int npaths;       // paths of this direction in one pair
+    int first;        // 1: S = L (first direction), 0: S += L
+};
+
+// Path p of direction (dx,dy): start pixel and length.  A pixel starts a path iff
+// its predecessor is outside the image: the whole edge column x = (dx>0 ? 0 : w-1)
+// when dx != 0, plus the edge row y = (dy>0 ? 0 : h-1) when dy != 0 without the
+// corner the column already owns (the de-duplication at stereo_sgm.cc:216,234,252).
+// All values are wave-uniform and forced into SGPRs.
+struct PathGeom {
+    int x0, y0, len;
+    bool edge; // the whole path runs along an image edge (every pixel is a border pixel)
+};
+__device__ __forceinline__ PathGeom path_geometry(int p, int w, int h, int dx, int dy)
+{
+    const int xe = dx > 0 ? 0 : w - 1; // start column when the path starts on the column edge
+    const int ye = dy > 0 ? 0 : h - 1; // start row when it starts on the row edge
+    const bool on_col = (dy == 0) || (dx != 0 && p < h);
+    const int q = p - h;
+    int x0 = on_col ? xe : (dx == 0 ? p : (dx > 0 ? q + 1 : q));
+    int y0 = on_col ? p : ye;
+    const int sx = dx == 0 ? 0x7fffffff : (dx > 0 ? w - x0 : x0 + 1);
+    const int sy = dy == 0 ? 0x7fffffff : (dy > 0 ? h - y0 : y0 + 1);
+    PathGeom g;
+    g.x0 = __builtin_amdgcn_readfirstlane(x0);
+    g.y0 = __builtin_amdgcn_readfirstlane(y0);
+    g.len = __builtin_amdgcn_readfirstlane(sx < sy ? sx : sy);
+    g.edge = (dy == 0 && (g.y0 == 0 || g.y0 == h - 1)) || (dx == 0 && (g.x0 == 0 || g.x0 == w - 1));
+    return g;
+}
+
+__device__ __forceinline__ int border_index(int y, int x, int w, int h)
+{
+    if (y == 0)
+        return x;
+    if (y == h - 1)
+        return w + x;
+    if (x == 0)
+        return 2 * w + y;
+    return 2 * w + h + y;
+}
+
+// 2R cost bytes of one lane -> R packed uint16 pairs.
+template <int R> struct CRaw;
+template <> struct CRaw<1> { unsigned short v; };
+template <> struct CRaw<2> { u32 v; };
+template <> struct CRaw<4> { uint2 v; };
+template <int R> struct SRaw { u32 v[R]; };
+
+__device__ __forceinline__ void unpack_c(const CRaw<1> &c, u32 (&o)[1]) { o[0] = __builtin_amdgcn_perm(0u, (u32)c.v, 0x0c010c00u); }
+__device__ __forceinline__ void unpack_c(const CRaw<2> &c, u32 (&o)[2])
+{
+    o[0] = __builtin_amdgcn_perm(0u, c.v, 0x0c010c00u);
+    o[1] = __builtin_amdgcn_perm(0u, c.v, 0x0c030c02u);
+}
+__device__ __forceinline__ void unpack_c(const CRaw<4> &c, u32 (&o)[4])
+{
+    o[0] = __builtin_amdgcn_perm(0u, c.v.x, 0x0c010c00u);
+    o[1] = __builtin_amdgcn_perm(0u, c.v.x, 0x0c030c02u);
+    o[2] = __builtin_amdgcn_perm(0u, c.v.y, 0x0c010c00u);
+    o[3] = __builtin_amdgcn_perm(0u, c.v.y, 0x0c030c02u);
+}
+
+template <int R> __device__ __forceinline__ CRaw<R> load_c(const uint8_t *p);
+template <> __device__ __forceinline__ CRaw<1> load_c<1>(const uint8_t *p) { return CRaw<1>{*reinterpret_cast<const unsigned short *>(p)}; }
+template <> __device__ __forceinline__ CRaw<2> load_c<2>(const uint8_t *p) { return CRaw<2>{*reinterpret_cast<const u32 *>(p)}; }
+template <> __device__ __forceinline__ CRaw<4> load_c<4>(const uint8_t *p) { return CRaw<4>{*reinterpret_cast<const uint2 *>(p)}; }
+
+template <int R> __device__ __forceinline__ SRaw<R> load_s(const uint16_t *p);
+template <> __device__ __forceinline__ SRaw<1> load_s<1>(const uint16_t *p) { return SRaw<1>{{*reinterpret_cast<const u32 *>(p)}}; }
+template <> __device__ __forceinline__ SRaw<2> load_s<2>(const uint16_t *p)
+{
+    const uint2 t = *reinterpret_cast<const uint2 *>(p);
+    return SRaw<2>{{t.x, t.y}};
+}
+template <> __device__ __forceinline__ SRaw<4> load_s<4>(const uint16_t *p)
+{
+    const uint4 t = *reinterpret_cast<const uint4 *>(p);
+    return SRaw<4>{{t.x, t.y, t.z, t.w}};
+}
+template <int R> __device__ __forceinline__ void store_s(uint16_t *p, const u32 (&v)[R]);
+template <> __device__ __forceinline__ void store_s<1>(uint16_t *p, const u32 (&v)[1]) { *reinterpret_cast<u32 *>(p) = v[0]; }
+template <> __device__ __forceinline__ void store_s<2>(uint16_t *p, const u32 (&v)[2]) { *reinterpret_cast<uint2 *>(p) = make_uint2(v[0], v[1]); }
+template <> __device__ __forceinline__ void store_s<4>(uint16_t *p, const u32 (&v)[4]) { *reinterpret_cast<uint4 *>(p) = make_uint4(v[0], v[1], v[2], v[3]); }
+
+// One step of the recurrence for the R register pairs of a lane (stereo_sgm.h:129-146):
+// L = C + min(prior[d], prior[d-1]+P1, prior[d+1]+P1, m+P2) - m with m = min_k prior[k].
+template <int R>
+__device__ __forceinline__ void path_step_u16(const u32 (&prior)[R], const u32 (&c)[R], u32 P1p, u32 P2p, u32 (&L)[R])
+{
+    const u32 left = dpp<0x138>(INF2, prior[R - 1]); // lane-1's top pair; lane 0 has no d-1
+    const u32 right = dpp<0x130>(INF2, prior[0]);    // lane+1's bottom pair; lane 63 has no d+1
+    u32 mn = prior[0];
+#pragma unroll
+    for (int j = 1; j < R; j++)
+        mn = pk_min(mn, prior[j]);
+    const u32 m = wave_min_u32(min(mn & 0xFFFFu, mn >> 16));
+    const u32 mp = m * 0x10001u;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const u32 prev = __builtin_amdgcn_alignbit(prior[j], j ? prior[j - 1] : left, 16);
+        const u32 next = __builtin_amdgcn_alignbit(j < R - 1 ? prior[j + 1] : right, prior[j], 16);
+        const u32 A = pk_min(prior[j], pk_add(pk_min(prev, next), P1p));
+        L[j] = pk_add(pk_min(pk_sub(A, mp), P2p), c[j]);
+    }
+}
+
+template <int R, bool FIRST, bool HAS_PAD, int PF>
+__global__ __launch_bounds__(256) void aggregate_u16_kernel(const AggArgs a)
+{
+    constexpr int Dp = 128 * R;
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (p >= a.npaths)
+        return;
+    const int w = a.w, h = a.h;
+    const size_t npix = (size_t)w * h;
+    const unsigned loff = lane * (2 * R); // this lane's first disparity
+    // wave-uniform bases; per-lane part is the 32-bit offset loff (saddr + voffset addressing)
+    const uint8_t *Cf = static_cast<const uint8_t *>(a.C) + (size_t)blockIdx.y * npix * Dp;
+    uint16_t *Sf = static_cast<uint16_t *>(a.S) + (size_t)blockIdx.y * npix * Dp;
+    uint16_t *BLf = static_cast<uint16_t *>(a.BL) + (size_t)blockIdx.y * (size_t)(2 * w + 2 * h) * Dp;
+
+    const PathGeom g = path_geometry(p, w, h, a.dx, a.dy);
+    const int len = g.len;
+    const int stride = (a.dy * w + a.dx) * Dp; // voxels per step; one pair holds < 2^31 voxels
+    const int off0 = (g.y0 * w + g.x0) * Dp;
+
+    const u32 P1p = (u32)a.P1 * 0x10001u, P2p = (u32)a.P2 * 0x10001u;
+    u32 padfloor[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int d = (int)loff + 2 * j;
+        padfloor[j] = (d >= a.D ? INF16 : 0u) | (d + 1 >= a.D ? INF16 << 16 : 0u);
+    }
+
+    // ---- step 0, the start pixel: buf += C (stereo_sgm.cc:201,218,236,254); buf is
+    // L_{k-1} there (zero before the first direction, stereo_sgm.cc:46)
+    u32 prior[R];
+    {
+        uint16_t *blp = BLf + (size_t)border_index(g.y0, g.x0, w, h) * Dp;
+        const SRaw<R> bl = load_s<R>(blp + loff);
+        u32 c[R];
+        unpack_c(load_c<R>(Cf + off0 + loff), c);
+        SRaw<R> s;
+        if (!FIRST)
+            s = load_s<R>(Sf + off0 + loff);
+        u32 sn[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            prior[j] = pk_add(bl.v[j], c[j]);
+            if (HAS_PAD)
+                prior[j] = pk_max(prior[j], padfloor[j]);
+            sn[j] = FIRST ? prior[j] : pk_add(s.v[j], prior[j]);
+        }
+        store_s<R>(Sf + off0 + loff, sn);
+        store_s<R>(blp + loff, prior);
+    }
+    if (len == 1)
+        return;
+
+    // ---- steps 1 .. len-1; ring slot i holds a step t with (t-1) % PF == i
+    CRaw<R> cq[PF];
+    SRaw<R> sq[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        const int o = off0 + (1 + i < len ? 1 + i : len - 1) * stride;
+        cq[i] = load_c<R>(Cf + o + loff);
+        if (!FIRST)
+            sq[i] = load_s<R>(Sf + o + loff);
+    }
+    const int xl = g.x0 + (len - 1) * a.dx, yl = g.y0 + (len - 1) * a.dy; // last pixel
+    uint16_t *bl_last = BLf + (size_t)border_index(yl, xl, w, h) * Dp;
+
+    int o = off0; // voxel offset of the current step, advanced by the step lambda
+    auto step = [&](int t, int i, bool prefetch) {
+        o += stride;
+        u32 c[R];
+        unpack_c(cq[i], c);
+        SRaw<R> s;
+        if (!FIRST)
+            s = sq[i];
+        if (prefetch) { // stream the volume PF steps ahead
+            const int o2 = o + PF * stride;
+            cq[i] = load_c<R>(Cf + o2 + loff);
+            if (!FIRST)
+                sq[i] = load_s<R>(Sf + o2 + loff);
+        }
+        u32 L[R];
+        path_step_u16<R>(prior, c, P1p, P2p, L);
+        u32 sn[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (HAS_PAD)
+                L[j] = pk_max(L[j], padfloor[j]);
+            sn[j] = FIRST ? L[j] : pk_add(s.v[j], L[j]);
+            prior[j] = L[j];
+        }
+        store_s<R>(Sf + o + loff, sn);
+        if (g.edge) { // path along an image edge: every pixel feeds a later direction's start
+            const int x = g.x0 + t * a.dx, y = g.y0 + t * a.dy;
+            store_s<R>(BLf + (size_t)border_index(y, x, w, h) * Dp + loff, L);
+        } else if (t == len - 1) {
+            store_s<R>(bl_last + loff, L);
+        }
+    };
+
+    int t = 1;
+    for (; t + 2 * PF <= len; t += PF) { // every prefetch target t+i+PF <= len-1
+#pragma unroll
+        for (int i = 0; i < PF; i++)
+            step(t + i, i, true);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+        if (t + i < len)
+            step(t + i, i, t + i + PF < len);
+    t += PF;
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+        if (t + i < len)
+            step(t + i, i, false);
+}
+
+// ---------------------------------------------------------------------------
+// K3f path aggregation, float build (float C, L, S).  sgm.cc:177-254, sgm.h:129-157.
+// Lane l holds d = 2Rl .. 2Rl+2R-1 as 2R floats.  Same op order as the reference:
+// e = mp + P2; e = min(e, prior[d]); e = min(e, prior[d-1] + P1); e = min(e,
+// prior[d+1] + P1); L = C + (e - mp).  No multiply anywhere, so no contraction.
+// ---------------------------------------------------------------------------
+template <int R, bool FIRST, bool HAS_PAD, int PF>
+__global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
+{
+    constexpr int N = 2 * R; // floats per lane
+    constexpr int Dp = 64 * N;
+    typedef float fvec __attribute__((ext_vector_type(N)));
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (p >= a.npaths)
+        return;
+    const int w = a.w, h = a.h;
+    const size_t npix = (size_t)w * h;
+    const unsigned loff = lane * N;
+    const float *Cf = static_cast<const float *>(a.C) + (size_t)blockIdx.y * npix * Dp;
+    float *Sf = static_cast<float *>(a.S) + (size_t)blockIdx.y * npix * Dp;
+    float *BLf = static_cast<float *>(a.BL) + (size_t)blockIdx.y * (size_t)(2 * w + 2 * h) * Dp;
+
+    const PathGeom g = path_geometry(p, w, h, a.dx, a.dy);
+    const int len = g.len;
+    const int stride = (a.dy * w + a.dx) * Dp; // voxels per step; one pair holds < 2^31 voxels
+    const int off0 = (g.y0 * w + g.x0) * Dp;
+    const float P1f = (float)a.P1, P2f = (float)a.P2;
+    const float inf = __builtin_inff();
+
+    auto ld = [](const float *q) { return *reinterpret_cast<const fvec *>(q); };
+    auto st = [](float *q, const float (&v)[N]) {
+        fvec t;
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            t[j] = v[j];
+        *reinterpret_cast<fvec *>(q) = t;
+    };
+
+    float prior[N];
+    {
+        const size_t bo = (size_t)border_index(g.y0, g.x0, w, h) * Dp + loff;
+        const fvec bl = ld(BLf + bo);
+        const fvec c = ld(Cf + off0 + loff);
+        fvec s;
+        if (!FIRST)
+            s = ld(Sf + off0 + loff);
+        float sn[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            prior[j] = bl[j] + c[j]; // sgm.h:95-102 sum_vectors on the start pixel
+            if (HAS_PAD && (int)loff + j >= a.D)
+                prior[j] = inf;
+            sn[j] = FIRST ? prior[j] : s[j] + prior[j];
+        }
+        st(Sf + off0 + loff, sn);
+        st(BLf + bo, prior);
+    }
+    if (len == 1)
+        return;
+
+    fvec cq[PF], sq[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        const int o = off0 + (1 + i < len ? 1 + i : len - 1) * stride;
+        cq[i] = ld(Cf + o + loff);
+        if (!FIRST)
+            sq[i] = ld(Sf + o + loff);
+    }
+    const int xl = g.x0 + (len - 1) * a.dx, yl = g.y0 + (len - 1) * a.dy;
+    const size_t bl_last = (size_t)border_index(yl, xl, w, h) * Dp;
+
+    int o = off0;
+    auto step = [&](int t, int i, bool prefetch) {
+        o += stride;
+        const fvec c = cq[i];
+        fvec s;
+        if (!FIRST)
+            s = sq[i];
+        if (prefetch) {
+            const int o2 = o + PF * stride;
+            cq[i] = ld(Cf + o2 + loff);
+            if (!FIRST)
+                sq[i] = ld(Sf + o2 + loff);
+        }
+        const float left = __builtin_bit_cast(float, dpp<0x138>(__builtin_bit_cast(u32, inf), __builtin_bit_cast(u32, prior[N - 1])));
+        const float right = __builtin_bit_cast(float, dpp<0x130>(__builtin_bit_cast(u32, inf), __builtin_bit_cast(u32, prior[0])));
+        float mn = prior[0];
+#pragma unroll
+        for (int j = 1; j < N; j++)
+            mn = fminf(mn, prior[j]);
+        const float mp = wave_min_f32(mn);
+        const float e0 = mp + P2f;
+        float L[N], sn[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const float pv = j ? prior[j - 1] : left;
+            const float nx = j < N - 1 ? prior[j + 1] : right;
+            float e = fminf(e0, prior[j]);
+            e = fminf(e, pv + P1f);
+            e = fminf(e, nx + P1f);
+            L[j] = c[j] + (e - mp);
+            if (HAS_PAD && (int)loff + j >= a.D)
+                L[j] = inf;
+            sn[j] = FIRST ? L[j] : s[j] + L[j];
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            prior[j] = L[j];
+        st(Sf + o + loff, sn);
+        if (g.edge) {
+            const int x = g.x0 + t * a.dx, y = g.y0 + t * a.dy;
+            st(BLf + (size_t)border_index(y, x, w, h) * Dp + loff, L);
+        } else if (t == len - 1) {
+            st(BLf + bl_last + loff, L);
+        }
+    };
+
+    int t = 1;
+    for (; t + 2 * PF <= len; t += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++)
+            step(t + i, i, true);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+        if (t + i < len)
+            step(t + i, i, t + i + PF < len);
+    t += PF;
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+        if (t + i < len)
+            step(t + i, i, false);
+}
+
+// ---------------------------------------------------------------------------
+// K4+K5 winner-takes-all, left-right check, subpixel.  stereo_sgm.h:209-241,
+// 275-317 (sgm.h:219-251,285-332 for float).  One workgroup per image row.
+//  pass 1: one wave per pixel x: first-min argmin over d (key = cost<<16|d, so the
+//          smaller d wins ties like the strict '<' scan) and, for the right view,
+//          an LDS atomic min of the same keys into slot x-d -- the reference's
+//          diagonal scan S[y][xr+i][i] regrouped by xr.
+//  pass 2: one thread per pixel: LR test |d - dR(x-d)| > 2, equiangular subpixel
+//          in float32, 256.0 * (double), round half away, uint16.
+// Float keys: a monotone float->uint32 map in the high word of a 64-bit key.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t subpixel_u16(int d, int D, float cl, float cc, float cr, bool *undefined)
+{
+    if (d >= 1 && d < D - 1) {
+        const float num = 0.5f * (cr - cl);
+        const float den = (cr < cl) ? (cc - cl) : (cc - cr);
+        const float ds = (float)((double)num / (double)den); // correctly rounded float quotient
+        const float dsub = (float)d + ds;
+        const double r = round(256.0 * (double)dsub);
+        if (!(r >= 0.0 && r <= 65535.0)) { // NaN / out of range: undefined cast in the reference
+            if (undefined)
+                *undefined = true;
+            return 0;
+        }
+        return (uint16_t)r;
+    }
+    return (uint16_t)(256 * d);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void wta_u16_kernel(const uint16_t *__restrict__ S, int w, int h, int D, int m,
+                                                      uint16_t *__restrict__ raw)
+{
+    constexpr int Dp = 128 * R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *rkey = reinterpret_cast<u32 *>(smem);       // [w] right-view best key
+    u32 *lkey = rkey + w;                            // [w] left-view best key
+    const int y = blockIdx.x;
+    const int W = w + 2 * m;
+    const uint16_t *Srow = S + ((size_t)blockIdx.y * h + y) * (size_t)w * Dp;
+    uint16_t *out = raw + ((size_t)blockIdx.y * (h + 2 * m) + (y + m)) * (size_t)W + m;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int x = threadIdx.x; x < w; x += blockDim.x)
+        rkey[x] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int x = wave; x < w; x += 4) {
+        const SRaw<R> s = load_s<R>(Srow + (size_t)x * Dp + lane * 2 * R);
+        u32 best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 2 * R; j++) {
+            const int d = lane * 2 * R + j;
+            const u32 v = (j & 1) ? (s.v[j >> 1] >> 16) : (s.v[j >> 1] & 0xFFFFu);
+            if (d < D) {
+                const u32 key = (v << 16) | (u32)d;
+                best = min(best, key);
+                if (d <= x)
+                    atomicMin(&rkey[x - d], key);
+            }
+        }
+        best = wave_min_u32(best);
+        if (lane == 0)
+            lkey[x] = best;
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+        const int d = (int)(lkey[x] & 0xFFFFu);
+        uint16_t o = 0;
+        if (x - d >= 0) {
+            const int dr = (int)(rkey[x - d] & 0xFFFFu);
+            if (abs(d - dr) <= 2) {
+                float cl = 0.f, cc = 0.f, cr = 0.f;
+                if (d >= 1 && d < D - 1) {
+                    const uint16_t *v = Srow + (size_t)x * Dp + d;
+                    cl = (float)v[-1];
+                    cc = (float)v[0];
+                    cr = (float)v[1];
+                }
+                o = subpixel_u16(d, D, cl, cc, cr, nullptr);
+            }
+        }
+        out[x] = o;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void wta_f32_kernel(const float *__restrict__ S, int w, int h, int D,
+                                                      uint16_t *__restrict__ raw)
+{
+    constexpr int N = 2 * R;
+    constexpr int Dp = 64 * N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *rkey = reinterpret_cast<unsigned long long *>(smem);
+    unsigned long long *lkey = rkey + w;
+    const int y = blockIdx.x;
+    const float *Srow = S + ((size_t)blockIdx.y * h + y) * (size_t)w * Dp;
+    uint16_t *out = raw + ((size_t)blockIdx.y * h + y) * (size_t)w;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int x = threadIdx.x; x < w; x += blockDim.x)
+        rkey[x] = ~0ull;
+    __syncthreads();
+    typedef float fvec __attribute__((ext_vector_type(N)));
+    for (int x = wave; x < w; x += 4) {
+        const fvec s = *reinterpret_cast<const fvec *>(Srow + (size_t)x * Dp + lane * N);
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const int d = lane * N + j;
+            if (d < D) {
+                const unsigned long long key = ((unsigned long long)float_key(s[j]) << 32) | (u32)d;
+                best = key < best ? key : best;
+                if (d <= x)
+                    atomicMin(&rkey[x - d], key);
+            }
+        }
+        // 64-bit wave min: high words first, then low words among the lanes that tie
+        const u32 hi = wave_min_u32((u32)(best >> 32));
+        const u32 lo = wave_min_u32((u32)(best >> 32) == hi ? (u32)best : 0xFFFFFFFFu);
+        if (lane == 0)
+            lkey[x] = ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+        const int d = (int)(lkey[x] & 0xFFFFFFFFull);
+        uint16_t o = 0;
+        if (x - d >= 0) {
+            const int dr = (int)(rkey[x - d] & 0xFFFFFFFFull);
+            if (abs(d - dr) <= 2) {
+                float cl = 0.f, cc = 0.f, cr = 0.f;
+                if (d >= 1 && d < D - 1) {
+                    const float *v = Srow + (size_t)x * Dp + d;
+                    cl = v[-1];
+                    cc = v[0];
+                    cr = v[1];
+                }
+                o = subpixel_u16(d, D, cl, cc, cr, nullptr);
+            }
+        }
+        out[x] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6 3x3 median, replicate border (cv::medianBlur(disp, disp, 3) at
+// stereo_sgm.cc:187 / sgm.cc:172).  One thread per pixel, 19-exchange network.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(u32 &a, u32 &b)
+{
+    const u32 lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+
+__global__ __launch_bounds__(256) void median3_kernel(const uint16_t *__restrict__ in, int W, int H,
+                                                      uint16_t *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W)
+        return;
+    const uint16_t *img = in + (size_t)blockIdx.z * W * H;
+    const int xm = x > 0 ? x - 1 : 0, xp = x < W - 1 ? x + 1 : W - 1;
+    const int ym = y > 0 ? y - 1 : 0, yp = y < H - 1 ? y + 1 : H - 1;
+    u32 v0 = img[(size_t)ym * W + xm], v1 = img[(size_t)ym * W + x], v2 = img[(size_t)ym * W + xp];
+    u32 v3 = img[(size_t)y * W + xm], v4 = img[(size_t)y * W + x], v5 = img[(size_t)y * W + xp];
+    u32 v6 = img[(size_t)yp * W + xm], v7 = img[(size_t)yp * W + x], v8 = img[(size_t)yp * W + xp];
+    cswap(v1, v2); cswap(v4, v5); cswap(v7, v8);
+    cswap(v0, v1); cswap(v3, v4); cswap(v6, v7);
+    cswap(v1, v2); cswap(v4, v5); cswap(v7, v8);
+    cswap(v0, v3); cswap(v5, v8); cswap(v4, v7);
+    cswap(v3, v6); cswap(v1, v4); cswap(v2, v5);
+    cswap(v4, v7); cswap(v4, v2); cswap(v6, v4);
+    cswap(v4, v2);
+    out[((size_t)blockIdx.z * H + y) * W + x] = (uint16_t)v4;
+}
+
+// ---------------------------------------------------------------------------
+// Small helpers: layout conversion for taps / the float input, debug WTA on C,
+// Hamming matrix (core/hamming.c:215-236).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void repitch_kernel(const T *__restrict__ src, int Dsrc, T *__restrict__ dst, int Ddst,
+                                                      size_t npix, T fill)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npix * (size_t)Ddst)
+        return;
+    const size_t pix = t / Ddst;
+    const int d = (int)(t - pix * Ddst);
+    dst[t] = d < Dsrc ? src[pix * Dsrc + d] : fill;
+}
+
+__global__ __launch_bounds__(256) void data_cost_wta_kernel(const uint8_t *__restrict__ C, int w, int h, int D, int Dp,
+                                                            int m, uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w)
+        return;
+    const uint8_t *v = C + ((size_t)y * w + x) * Dp;
+    int d = 0;
+    for (int i = 1; i < D; i++)
+        if (v[i] < v[d])
+            d = i;
+    out[(size_t)(y + m) * (w + 2 * m) + (x + m)] = (uint8_t)d;
+}
+
+__global__ __launch_bounds__(256) void hamming_matrix_kernel(uint16_t *__restrict__ dis, const uint8_t *__restrict__ a,
+                                                             const uint8_t *__restrict__ b, int na, int nb, int ncodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= na || j >= nb)
+        return;
+    const uint8_t *pa = a + (size_t)i * ncodes, *pb = b + (size_t)j * ncodes;
+    u32 s = 0;
+    int k = 0;
+    if ((ncodes & 3) == 0)
+        for (; k < ncodes; k += 4)
+            s += __builtin_popcount(*reinterpret_cast<const u32 *>(pa + k) ^ *reinterpret_cast<const u32 *>(pb + k));
+    for (; k < ncodes; k++)
+        s += __builtin_popcount((u32)(pa[k] ^ pb[k]));
+    dis[(size_t)j * na + i] = (uint16_t)s;
+}
+
+} // namespace sgmx

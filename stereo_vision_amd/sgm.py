@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's SGM interface on top of the C ABI.
+
+    reference (C++)                                   here
+    recon::StereoSGMParams  (stereo_sgm.h:15-21)      StereoSGMParams
+    recon::StereoSGM(params).compute(L, R, disp)      StereoSGM(params).compute(L, R) -> disp
+    recon::SGMParams        (sgm.h:18-23)             SGMParams
+    recon::SGM(params).Compute(left_path, right_path) SGM(params).Compute(left_path, right_path)
+                                                      SGM(params).compute_cost(volume)
+
+Same field names and argument meaning; errors are exceptions (SgmxError) where the
+reference asserts / throws / has undefined behaviour.  All arithmetic happens in
+libsgmx.so on the GPU; numpy is only used to hold host buffers.
+"""
+import ctypes as C
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import SgmxError, SgmxParams
+
+
+@dataclass
+class StereoSGMParams:
+    disp_range: int = 128
+    window_sz: int = 5
+    penalty1: int = 3
+    penalty2: int = 60
+    # extensions: not in the reference struct
+    num_paths: int = 8
+    device: int = 0
+    max_batch: int = 1
+
+
+SGMParams = StereoSGMParams  # sgm.h:18-23 has the same four ints
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    """Owns one sgmx context."""
+
+    def __init__(self, params):
+        self.lib = _lib.load()
+        self.params = params
+        p = SgmxParams(params.disp_range, params.window_sz, params.penalty1, params.penalty2, params.num_paths,
+                       params.device, params.max_batch, 0)
+        h = C.c_void_p()
+        rc = self.lib.sgmx_create(C.byref(p), C.byref(h))
+        if rc != 0:
+            raise SgmxError(rc, self.lib.sgmx_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sgmx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def check(self, rc):
+        if rc != 0:
+            raise SgmxError(rc, self.lib.sgmx_last_error(self.h).decode())
+
+    @property
+    def margin(self):
+        return (self.params.window_sz - 1) // 2
+
+    # ---- measurement ----
+    def set_profiling(self, on):
+        self.check(self.lib.sgmx_set_profiling(self.h, int(on)))
+
+    def kernel_stats(self):
+        out = {}
+        for k, name in enumerate(_lib.KERNEL_CLASS_NAMES):
+            ms, n = C.c_double(), C.c_long()
+            self.check(self.lib.sgmx_kernel_stats(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def algorithmic_bytes(self, W, H):
+        agg = C.c_double()
+        tot = self.lib.sgmx_algorithmic_bytes_census(self.h, W, H, C.byref(agg))
+        return tot, agg.value
+
+
+class StereoSGM(Engine):
+    """recon::StereoSGM (stereo_sgm.h:53-57), COST_CENSUS build."""
+
+    def compute(self, left_img, right_img):
+        """left/right: (H, W) uint8 (any row pitch) -> (H, W) uint16, 256 * disparity."""
+        left_img, right_img = np.asarray(left_img), np.asarray(right_img)
+        if left_img.dtype != np.uint8 or right_img.dtype != np.uint8 or left_img.ndim != 2:
+            raise ValueError("StereoSGM.compute wants single-channel uint8 images")
+        if left_img.shape != right_img.shape:
+            raise ValueError("left and right image sizes differ")
+        if left_img.strides[1] != 1:
+            left_img = np.ascontiguousarray(left_img)
+        if right_img.strides[1] != 1:
+            right_img = np.ascontiguousarray(right_img)
+        H, W = left_img.shape
+        disp = np.empty((H, W), np.uint16)
+        self.check(self.lib.sgmx_compute_census_u8(self.h, _ptr(left_img), _ptr(right_img), W, H,
+                                                   left_img.strides[0], right_img.strides[0], _ptr(disp), 2 * W))
+        return disp
+
+    def compute_batch(self, lefts, rights):
+        """(n, H, W) uint8 x2 -> (n, H, W) uint16; what the batch scripts do pair by pair."""
+        lefts = np.ascontiguousarray(lefts, np.uint8)
+        rights = np.ascontiguousarray(rights, np.uint8)
+        if lefts.shape != rights.shape or lefts.ndim != 3:
+            raise ValueError("want two (n, H, W) uint8 stacks of equal shape")
+        n, H, W = lefts.shape
+        disp = np.empty((n, H, W), np.uint16)
+        self.check(self.lib.sgmx_compute_census_u8_batch(self.h, n, _ptr(lefts), _ptr(rights), W, H, _ptr(disp)))
+        return disp
+
+    def compute_device(self, d_left, d_right, d_disp, n, W, H, stream=0):
+        """Device-resident batch: raw device pointers (ints), enqueue only."""
+        self.check(self.lib.sgmx_compute_census_u8_dev(self.h, n, d_left, d_right, W, H, d_disp, stream))
+
+    # ---- stage taps ----
+    def census(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        H, W = img.shape
+        m = self.margin
+        out = np.empty((H - 2 * m, W - 2 * m), np.uint32)
+        self.check(self.lib.sgmx_census_u32(self.h, _ptr(img), W, H, W, _ptr(out)))
+        return out
+
+    def hamming_volume(self, census_left, census_right):
+        cl = np.ascontiguousarray(census_left, np.uint32)
+        cr = np.ascontiguousarray(census_right, np.uint32)
+        h, w = cl.shape
+        out = np.empty((h, w, self.params.disp_range), np.uint8)
+        self.check(self.lib.sgmx_hamming_volume_u8(self.h, _ptr(cl), _ptr(cr), w, h, _ptr(out)))
+        return out
+
+    def hamming_matrix(self, a, b):
+        """compute_hamming (core/hamming.h:67-68): a (na, ncodes), b (nb, ncodes) -> (nb, na) uint16."""
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        out = np.empty((b.shape[0], a.shape[0]), np.uint16)
+        self.check(self.lib.sgmx_hamming_matrix_u16(self.h, _ptr(out), _ptr(a), _ptr(b), a.shape[0], b.shape[0],
+                                                    a.shape[1]))
+        return out
+
+    def stages(self, H, W, index=0):
+        m = self.margin
+        h, w, D = H - 2 * m, W - 2 * m, self.params.disp_range
+        Cv = np.empty((h, w, D), np.uint8)
+        S = np.empty((h, w, D), np.uint16)
+        raw = np.empty((H, W), np.uint16)
+        self.check(self.lib.sgmx_get_stages_census(self.h, index, _ptr(Cv), _ptr(S), _ptr(raw)))
+        return dict(C=Cv, S=S, raw=raw)
+
+    def data_cost_image(self, H, W, index=0):
+        out = np.empty((H, W), np.uint8)
+        self.check(self.lib.sgmx_get_data_cost_wta_u8(self.h, index, _ptr(out)))
+        return out
+
+
+def load_representation(path):
+    """SGM::LoadRepresentationFromFile (sgm.h:378-410): int32 dims (= 3), uint64 size[3]
+    = {H, W, K}, float32[H][W][K]."""
+    with open(path, "rb") as f:
+        (dims,) = struct.unpack("<i", f.read(4))
+        if dims != 3:
+            raise ValueError("descriptor file: dims != 3")  # the reference does `throw 1` (sgm.h:391)
+        size = struct.unpack("<3Q", f.read(24))
+        data = np.fromfile(f, np.float32, int(np.prod(size)))
+    if data.size != int(np.prod(size)):
+        raise ValueError("descriptor file truncated")
+    return data.reshape(size)
+
+
+class SGM(Engine):
+    """recon::SGM (sgm.h:61-65), COST_CNN build: float data cost."""
+
+    def compute_cost(self, cost):
+        """cost: (H, W, D) float32 data-cost volume (what sgm.cc:76-84 builds) -> (H, W) uint16."""
+        cost = np.ascontiguousarray(cost, np.float32)
+        H, W, D = cost.shape
+        disp = np.empty((H, W), np.uint16)
+        self.check(self.lib.sgmx_compute_cost_f32(self.h, _ptr(cost), W, H, D, _ptr(disp)))
+        return disp
+
+    def compute_cost_device(self, d_cost, d_disp, n, W, H, stream=0):
+        self.check(self.lib.sgmx_compute_cost_f32_dev(self.h, n, d_cost, W, H, self.params.disp_range, d_disp, stream))
+
+    def stages(self, H, W, index=0):
+        S = np.empty((H, W, self.params.disp_range), np.float32)
+        raw = np.empty((H, W), np.uint16)
+        self.check(self.lib.sgmx_get_stages_f32(self.h, index, _ptr(S), _ptr(raw)))
+        return dict(S=S, raw=raw)

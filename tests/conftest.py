@@ -53,4 +53,6 @@ def synth_pair(seed, H, W, max_disp, noise=2.0):
         d = int(rng.integers(0, max(1, max_disp)))
         right[b:b + nb] = base[2 + b:2 + min(H, b + nb), 2 + d:2 + d + W]
     right = right + rng.normal(0, noise, size=right.shape)
-    return (np.clip(left, 0, 255).astype(np.uint8), np.clip(right, 0, 255).astype(np.uint8))
+    # apply_along_axis leaves Fortran-ordered arrays behind; device uploads need dense C order
+    return (np.ascontiguousarray(np.clip(left, 0, 255).astype(np.uint8)),
+            np.ascontiguousarray(np.clip(right, 0, 255).astype(np.uint8)))

@@ -1,0 +1,85 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/sgmx.h
+declares, validates parameters, and refuses to run without a GPU (no CPU fallback).
+No compute entry point is called here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from stereo_vision_amd import _lib
+from stereo_vision_amd._lib import SgmxParams
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sgmx.h")).read()
+    return sorted(set(re.findall(r"SGMX_API\s+[\w\s\*]+?\b(sgmx_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), name
+    # and the Python binding table covers exactly the header
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_version_string():
+    assert b"gfx950" in _lib.load().sgmx_version()
+
+
+def _create(**kw):
+    base = dict(disp_range=128, window_sz=5, penalty1=3, penalty2=60, num_paths=8, device=0, max_batch=1, flags=0)
+    base.update(kw)
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.sgmx_create(C.byref(SgmxParams(**base)), C.byref(h))
+    msg = lib.sgmx_last_error(None).decode()
+    if rc == 0:
+        lib.sgmx_destroy(h)
+    return rc, msg
+
+
+@pytest.mark.parametrize("kw", [dict(disp_range=1), dict(disp_range=513), dict(num_paths=5), dict(penalty1=-1),
+                                dict(window_sz=-3), dict(window_sz=4), dict(flags=7), dict(max_batch=-2)])
+def test_create_rejects_bad_parameters(kw):
+    rc, msg = _create(**kw)
+    assert rc == 1 and msg  # SGMX_ERR_INVALID_ARG, with text
+
+
+def test_create_rejects_penalties_beyond_uint16_guard():
+    # 36*255 + 8*P2 must fit uint16 (include/sgmx.h)
+    assert _create(penalty2=7045)[0] == 2
+    assert _create(penalty2=7044, penalty1=7044)[0] in (0, 3)  # valid: OK on a GPU box, NO_DEVICE here
+
+
+def test_null_arguments():
+    lib = _lib.load()
+    assert lib.sgmx_create(None, None) == 1
+    assert lib.sgmx_compute_census_u8(None, None, None, 8, 8, 8, 8, None, 16) == 1
+    assert lib.sgmx_set_profiling(None, 1) == 1
+    lib.sgmx_destroy(None)  # no-op
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc, msg = _create()
+    assert rc == 3 and "no CPU fallback" in msg
+    import stereo_vision_amd as sv
+    with pytest.raises(sv.SgmxError):
+        sv.StereoSGM(sv.StereoSGMParams())
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "stereo_vision_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
