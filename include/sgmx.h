@@ -57,8 +57,14 @@ typedef struct sgmx_params {
     int num_paths;   /* 8 (default; order of stereo_sgm.cc:120-122) or 4 (its axis-aligned subset) */
     int device;      /* HIP device ordinal (default 0)                                           */
     int max_batch;   /* stereo pairs processed per launch group (default 1); sizes the scratch   */
-    int flags;       /* reserved, must be 0                                                       */
+    int flags;       /* 0, or SGMX_FLAG_MATERIALIZE                                               */
 } sgmx_params;
+
+/* flags: keep the data-cost volume C and the summed-cost volume S in HBM as the reference does
+ * (one streaming pass over both per direction).  Without it -- and when penalty2 <= 255 -- the
+ * census path recomputes C from the census images and stores one byte per voxel and direction
+ * instead; the results are identical.  penalty2 > 255 always uses the materialised form. */
+#define SGMX_FLAG_MATERIALIZE 1
 
 typedef struct sgmx_ctx sgmx_ctx;
 

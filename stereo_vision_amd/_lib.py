@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgmx.so")
 
 SGMX_OK = 0
+FLAG_MATERIALIZE = 1  # SGMX_FLAG_MATERIALIZE
 ERR_NAMES = {1: "INVALID_ARG", 2: "RANGE", 3: "NO_DEVICE", 4: "HIP", 5: "OOM", 6: "STATE"}
 K_CENSUS, K_HAMMING, K_AGGREGATE, K_WTA, K_MEDIAN, K_COUNT = range(6)
 KERNEL_CLASS_NAMES = ["census", "hamming_volume", "aggregate", "wta", "median"]

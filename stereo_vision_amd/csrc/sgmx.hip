@@ -3,6 +3,7 @@
 // with SGMX_ERR_NO_DEVICE when no GPU is usable.
 #include "../../include/sgmx.h"
 #include "sgmx_kernels.hpp"
+#include "sgmx_kernels_v2.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -36,6 +37,8 @@ struct sgmx_ctx {
     int W = 0, H = 0;          // census: full image; float: volume size
     int w = 0, h = 0, m = 0;   // cropped
     int mode = 0;              // 0 none, 1 census, 2 float
+    bool fast = false;         // census path without C / S volumes (sgmx_kernels_v2.hpp): P2 <= 255
+    int wp = 0;                // row pitch of the padded right census image (fast path)
     int last_n = 0;            // pairs in the last launch group
 
     // device scratch (sized for max_batch pairs)
@@ -44,6 +47,9 @@ struct sgmx_ctx {
     void *d_C = nullptr;   // uint8 or float, pitch Dp
     void *d_S = nullptr;   // uint16 or float, pitch Dp
     void *d_BL = nullptr;  // border ring
+    uint8_t *d_E = nullptr;     // fast path: num_paths byte volumes, [k][max_batch][h][w][Dp]
+    uint16_t *d_SB = nullptr;   // fast path: border accumulator, same shape as d_BL
+    size_t bytes_E = 0;         // one pair of one direction
     uint16_t *d_raw = nullptr, *d_out = nullptr;
     size_t bytes_C = 0, bytes_S = 0, bytes_BL = 0;
 
@@ -75,7 +81,7 @@ int fail(sgmx_ctx *c, int code, const std::string &msg)
 
 void free_scratch(sgmx_ctx *c)
 {
-    void *ptrs[] = {c->d_left, c->d_right, c->d_cl, c->d_cr, c->d_C, c->d_S, c->d_BL, c->d_raw, c->d_out};
+    void *ptrs[] = {c->d_left, c->d_right, c->d_cl, c->d_cr, c->d_C, c->d_S, c->d_BL, c->d_raw, c->d_out, c->d_E, c->d_SB};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -83,6 +89,8 @@ void free_scratch(sgmx_ctx *c)
     c->d_cl = c->d_cr = nullptr;
     c->d_C = c->d_S = c->d_BL = nullptr;
     c->d_raw = c->d_out = nullptr;
+    c->d_E = nullptr;
+    c->d_SB = nullptr;
     c->mode = 0;
     c->W = c->H = 0;
 }
@@ -101,14 +109,23 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
     c->bytes_C = npix * c->Dp * esz_c;
     c->bytes_S = npix * c->Dp * esz_s;
     c->bytes_BL = (size_t)(2 * w + 2 * h) * c->Dp * esz_s;
+    const bool fast = mode == 1 && c->fast;
+    c->wp = fast ? w + c->Dp : w;
     if (mode == 1) {
         HIPCHK(c, hipMalloc((void **)&c->d_left, nfull * B));
         HIPCHK(c, hipMalloc((void **)&c->d_right, nfull * B));
         HIPCHK(c, hipMalloc((void **)&c->d_cl, npix * 4 * B));
-        HIPCHK(c, hipMalloc((void **)&c->d_cr, npix * 4 * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_cr, (size_t)c->wp * h * 4 * B));
+        HIPCHK(c, hipMemset(c->d_cr, 0, (size_t)c->wp * h * 4 * B)); // the padding columns are never written again
     }
-    HIPCHK(c, hipMalloc(&c->d_C, c->bytes_C * B));
-    HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * B));
+    if (fast) {
+        c->bytes_E = npix * c->Dp;
+        HIPCHK(c, hipMalloc((void **)&c->d_E, c->bytes_E * B * c->prm.num_paths));
+        HIPCHK(c, hipMalloc((void **)&c->d_SB, c->bytes_BL * B));
+    } else {
+        HIPCHK(c, hipMalloc(&c->d_C, c->bytes_C * B));
+        HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * B));
+    }
     HIPCHK(c, hipMalloc(&c->d_BL, c->bytes_BL * B));
     HIPCHK(c, hipMalloc((void **)&c->d_raw, nfull * 2 * B));
     HIPCHK(c, hipMalloc((void **)&c->d_out, nfull * 2 * B));
@@ -246,6 +263,109 @@ int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t s
     return SGMX_OK;
 }
 
+template <int R> void launch_agg2(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
+                                  uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a)
+{
+    constexpr int PF = 8;
+    if (first) {
+        if (pad)
+            hipLaunchKernelGGL((aggregate2_kernel<R, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+        else
+            hipLaunchKernelGGL((aggregate2_kernel<R, true, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+    } else {
+        if (pad)
+            hipLaunchKernelGGL((aggregate2_kernel<R, false, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+        else
+            hipLaunchKernelGGL((aggregate2_kernel<R, false, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+    }
+}
+
+SumArgs sum_args(const sgmx_ctx *c)
+{
+    SumArgs a;
+    a.cl = c->d_cl;
+    a.cr = c->d_cr;
+    a.E = c->d_E;
+    a.estride = c->bytes_E * c->prm.max_batch;
+    a.SB = c->d_SB;
+    a.w = c->w;
+    a.h = c->h;
+    a.D = c->prm.disp_range;
+    a.wp = c->wp;
+    a.N = c->prm.num_paths;
+    return a;
+}
+
+size_t wta2_lds_bytes(const sgmx_ctx *c) { return (size_t)4 * (64 / (8 * c->R)) * (c->Dp / 2) * 4 + (size_t)c->w * 16; }
+
+// Fast census path: the ordered direction sweeps writing byte volumes, then the fused
+// sum + WTA / LR / subpixel kernel and the median.
+int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
+{
+    const int np = c->prm.num_paths;
+    HIPCHK(c, hipMemsetAsync(c->d_BL, 0, c->bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
+    HIPCHK(c, hipMemsetAsync(c->d_SB, 0, c->bytes_BL * n, st));
+    const bool pad = c->prm.disp_range != c->Dp;
+    for (int k = 0; k < np; k++) {
+        Agg2Args a;
+        a.w = c->w;
+        a.h = c->h;
+        a.D = c->prm.disp_range;
+        a.wp = c->wp;
+        a.dx = np == 8 ? DIRS8[k][0] : DIRS4[k][0];
+        a.dy = np == 8 ? DIRS8[k][1] : DIRS4[k][1];
+        a.P1 = c->prm.penalty1;
+        a.P2 = c->prm.penalty2;
+        a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
+        const dim3 grid((a.npaths + 3) / 4, n);
+        uint8_t *Ek = c->d_E + (size_t)k * c->bytes_E * c->prm.max_batch;
+        ProfScope ps(c, SGMX_K_AGGREGATE, st);
+        if (c->R == 1)
+            launch_agg2<1>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+        else if (c->R == 2)
+            launch_agg2<2>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+        else
+            launch_agg2<4>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, SGMX_K_WTA, st);
+        const SumArgs sa = sum_args(c);
+        const size_t lds = wta2_lds_bytes(c);
+        const dim3 grid(c->h, n);
+        if (lds > 64 * 1024) { // beyond the default dynamic-LDS limit
+            const void *fn = c->R == 1 ? (const void *)wta2_kernel<1> : c->R == 2 ? (const void *)wta2_kernel<2> : (const void *)wta2_kernel<4>;
+            HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (c->R == 1)
+            hipLaunchKernelGGL(wta2_kernel<1>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+        else if (c->R == 2)
+            hipLaunchKernelGGL(wta2_kernel<2>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+        else
+            hipLaunchKernelGGL(wta2_kernel<4>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, SGMX_K_MEDIAN, st);
+        hipLaunchKernelGGL(median3_kernel, dim3((c->W + 255) / 256, c->H, n), dim3(256), 0, st, c->d_raw, c->W, c->H, d_disp);
+        HIPCHK(c, hipGetLastError());
+    }
+    return SGMX_OK;
+}
+
+// The data-cost volume of pair `index` of the last launch group, pitch Dp, into d_dst
+// (fast path: recomputed from the census images, which is all that path keeps).
+int materialize_cost(sgmx_ctx *c, int index, uint8_t *d_dst, hipStream_t st)
+{
+    const size_t npix = (size_t)c->w * c->h;
+    const size_t groups = npix * (c->Dp / 16);
+    hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                       c->d_cl + (size_t)index * npix, c->d_cr + (size_t)index * c->wp * c->h, c->wp, c->Dp, c->w, c->h,
+                       c->prm.disp_range, c->Dp, d_dst, groups);
+    HIPCHK(c, hipGetLastError());
+    return SGMX_OK;
+}
+
 // One launch group (n <= max_batch) of the census path, everything device resident.
 int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint16_t *d_disp, hipStream_t st)
 {
@@ -253,14 +373,19 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
     {
         ProfScope ps(c, SGMX_K_CENSUS, st);
         hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 2 * n), dim3(256), 0, st, dL, dR, n, W, H,
-                           c->prm.window_sz, c->d_cl, c->d_cr);
+                           c->prm.window_sz, c->d_cl, c->d_cr, c->wp, c->fast ? c->Dp : 0);
         HIPCHK(c, hipGetLastError());
+    }
+    if (c->fast) {
+        const int rc = run_fast(c, n, d_disp, st);
+        c->last_n = n;
+        return rc;
     }
     {
         ProfScope ps(c, SGMX_K_HAMMING, st);
         const size_t groups = (size_t)n * w * h * (c->Dp / 16);
         hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, c->d_cl,
-                           c->d_cr, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
+                           c->d_cr, w, 0, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
         HIPCHK(c, hipGetLastError());
     }
     int rc = run_aggregation(c, n, false, st);
@@ -280,6 +405,8 @@ int check_size(sgmx_ctx *c, int W, int H, bool census)
         return fail(c, SGMX_ERR_INVALID_ARG, "image smaller than the census window");
     if ((size_t)(W - 2 * m) * (H - 2 * m) * c->Dp >= (size_t)1 << 31)
         return fail(c, SGMX_ERR_INVALID_ARG, "cost volume of one pair exceeds 2^31 voxels");
+    if ((size_t)(W - 2 * m) * 16 + 8192 > 160 * 1024)
+        return fail(c, SGMX_ERR_INVALID_ARG, "image wider than the per-row LDS budget of the WTA kernel (9728 pixels)");
     return SGMX_OK;
 }
 
@@ -309,8 +436,9 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "window_sz must be odd and in [1, 31]");
     if (p.num_paths != 4 && p.num_paths != 8)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "num_paths must be 4 or 8");
-    if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 || p.flags != 0)
-        return fail(nullptr, SGMX_ERR_INVALID_ARG, "negative penalty, bad max_batch or non-zero flags");
+    if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 ||
+        (p.flags & ~SGMX_FLAG_MATERIALIZE) != 0)
+        return fail(nullptr, SGMX_ERR_INVALID_ARG, "negative penalty, bad max_batch or unknown flags");
     // uint16 guarantees: L_k <= 255*(k+1) + P2 on any pixel, so S <= 36*255 + 8*P2, and the
     // "no disparity" sentinel 0x7FFF must stay above every L + P1 (sgmx_kernels.hpp INF16).
     if (36LL * 255 + 8LL * p.penalty2 > 65535 || 9LL * 255 + p.penalty2 + p.penalty1 >= 0x7FFF ||
@@ -327,6 +455,7 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->prm = p;
     c->R = p.disp_range <= 128 ? 1 : (p.disp_range <= 256 ? 2 : 4);
     c->Dp = 128 * c->R;
+    c->fast = p.penalty2 <= 255 && !(p.flags & SGMX_FLAG_MATERIALIZE);
     if (hipSetDevice(p.device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
         delete c;
         return fail(nullptr, SGMX_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
@@ -515,7 +644,7 @@ int sgmx_census_u32(sgmx_ctx *c, const uint8_t *img, int W, int H, int stride, u
     hipStream_t st = c->own_stream;
     hipError_t e = hipMemcpy2DAsync(d_img, W, img, stride, W, H, hipMemcpyHostToDevice, st);
     hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 1), dim3(256), 0, st, d_img, d_img, 1, W, H,
-                       c->prm.window_sz, d_o, d_o + (size_t)w * h);
+                       c->prm.window_sz, d_o, d_o + (size_t)w * h, w, 0);
     if (e == hipSuccess)
         e = hipMemcpyAsync(out, d_o, (size_t)w * h * 4, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
@@ -548,7 +677,7 @@ int sgmx_hamming_volume_u8(sgmx_ctx *c, const uint32_t *cl, const uint32_t *cr, 
     if (e == hipSuccess) {
         const size_t groups = npix * (Dp / 16);
         hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, d_c,
-                           d_c + npix, w, h, D, Dp, d_v, groups);
+                           d_c + npix, w, 0, w, h, D, Dp, d_v, groups);
         const size_t tot = npix * D;
         hipLaunchKernelGGL(repitch_kernel<uint8_t>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_v, Dp, d_o,
                            D, npix, (uint8_t)0);
@@ -612,15 +741,39 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
     hipStream_t st = c->own_stream;
     hipError_t e = hipSuccess;
     const unsigned nb = (unsigned)((tot + 255) / 256);
+    const bool fast = mode == 1 && c->fast;
     if (C && mode == 1) {
-        hipLaunchKernelGGL(repitch_kernel<uint8_t>, dim3(nb), dim3(256), 0, st,
-                           (const uint8_t *)c->d_C + index * c->bytes_C, Dp, (uint8_t *)tmp, D, npix, (uint8_t)0);
+        const uint8_t *src = (const uint8_t *)c->d_C + index * c->bytes_C;
+        uint8_t *vol = nullptr;
+        if (fast) { // this path keeps no volume: rebuild it from the census images
+            if (hipMalloc((void **)&vol, npix * Dp) != hipSuccess || materialize_cost(c, index, vol, st) != SGMX_OK) {
+                (void)hipFree(tmp);
+                (void)hipFree(vol);
+                return fail(c, SGMX_ERR_OOM, "stage tap: cannot rebuild the data-cost volume");
+            }
+            src = vol;
+        }
+        hipLaunchKernelGGL(repitch_kernel<uint8_t>, dim3(nb), dim3(256), 0, st, src, Dp, (uint8_t *)tmp, D, npix,
+                           (uint8_t)0);
         e = hipMemcpyAsync(C, tmp, tot * esz_c, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess)
             e = hipStreamSynchronize(st);
+        else
+            (void)hipStreamSynchronize(st);
+        (void)hipFree(vol);
     }
     if (S && e == hipSuccess) {
-        if (mode == 1)
+        if (fast) {
+            const SumArgs sa = sum_args(c);
+            const size_t thr = npix * (size_t)(8 * c->R);
+            const dim3 grid((unsigned)((thr + 255) / 256));
+            if (c->R == 1)
+                hipLaunchKernelGGL(sums_tap_kernel<1>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
+            else if (c->R == 2)
+                hipLaunchKernelGGL(sums_tap_kernel<2>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
+            else
+                hipLaunchKernelGGL(sums_tap_kernel<4>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
+        } else if (mode == 1)
             hipLaunchKernelGGL(repitch_kernel<uint16_t>, dim3(nb), dim3(256), 0, st,
                                (const uint16_t *)((const uint8_t *)c->d_S + index * c->bytes_S), Dp, (uint16_t *)tmp, D,
                                npix, (uint16_t)0);
@@ -665,12 +818,23 @@ int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
     HIPCHK(c, hipMalloc((void **)&d_o, nfull));
     hipStream_t st = c->own_stream;
     hipError_t e = hipMemsetAsync(d_o, 0, nfull, st);
-    hipLaunchKernelGGL(data_cost_wta_kernel, dim3((c->w + 255) / 256, c->h), dim3(256), 0, st,
-                       (const uint8_t *)c->d_C + index * c->bytes_C, c->w, c->h, c->prm.disp_range, c->Dp, c->m, d_o);
+    const uint8_t *src = (const uint8_t *)c->d_C + index * c->bytes_C;
+    uint8_t *vol = nullptr;
+    if (c->fast) {
+        if (hipMalloc((void **)&vol, (size_t)c->w * c->h * c->Dp) != hipSuccess || materialize_cost(c, index, vol, st) != SGMX_OK) {
+            (void)hipFree(d_o);
+            (void)hipFree(vol);
+            return fail(c, SGMX_ERR_OOM, "data-cost WTA tap: cannot rebuild the data-cost volume");
+        }
+        src = vol;
+    }
+    hipLaunchKernelGGL(data_cost_wta_kernel, dim3((c->w + 255) / 256, c->h), dim3(256), 0, st, src, c->w, c->h,
+                       c->prm.disp_range, c->Dp, c->m, d_o);
     if (e == hipSuccess)
         e = hipMemcpyAsync(out, d_o, nfull, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
     (void)hipFree(d_o);
+    (void)hipFree(vol);
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, SGMX_ERR_HIP, std::string("data-cost WTA tap: ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return SGMX_OK;

@@ -75,9 +75,11 @@ __device__ __forceinline__ float wave_min_f32(float x) { return key_float(wave_m
 // K1 census transform.  One thread per cropped pixel; z = image index (n left
 // images then n right images).  stereo_costs.cc:36-61.
 // ---------------------------------------------------------------------------
+// The right census image may be stored with a row pitch wpr >= w and a column offset xoffr (the
+// padded layout of sgmx_kernels_v2.hpp); the dense layout is wpr = w, xoffr = 0.
 __global__ __launch_bounds__(256) void census_kernel(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
                                                      int n, int W, int H, int wsz, u32 *__restrict__ cens_left,
-                                                     u32 *__restrict__ cens_right)
+                                                     u32 *__restrict__ cens_right, int wpr, int xoffr)
 {
     const int m = (wsz - 1) / 2;
     const int w = W - 2 * m, h = H - 2 * m;
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(256) void census_kernel(const uint8_t *__restrict__
     if (x >= w || y >= h)
         return;
     const uint8_t *img = (z < n ? left + (size_t)z * W * H : right + (size_t)(z - n) * W * H);
-    u32 *out = (z < n ? cens_left + (size_t)z * w * h : cens_right + (size_t)(z - n) * w * h);
+    u32 *out = (z < n ? cens_left + (size_t)z * w * h + (size_t)y * w
+                      : cens_right + (size_t)(z - n) * wpr * h + (size_t)y * wpr + xoffr);
     const int cy = y + m, cx = x + m;
     const uint8_t c = img[(size_t)cy * W + cx];
     u32 code = 0;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void census_kernel(const uint8_t *__restrict__
             code = (code << 1) + (row[px] > c ? 1u : 0u);
         }
     }
-    out[(size_t)y * w + x] = code;
+    out[x] = code;
 }
 
 // ---------------------------------------------------------------------------
@@ -108,8 +111,9 @@ __global__ __launch_bounds__(256) void census_kernel(const uint8_t *__restrict__
 // stereo_sgm.cc:43,75-101 + stereo_costs.h:120-132.  Pad disparities d >= D get 0.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hamming_volume_kernel(const u32 *__restrict__ cens_left,
-                                                             const u32 *__restrict__ cens_right, int w, int h, int D,
-                                                             int Dp, uint8_t *__restrict__ C, size_t total_groups)
+                                                             const u32 *__restrict__ cens_right, int wpr, int xoffr,
+                                                             int w, int h, int D, int Dp, uint8_t *__restrict__ C,
+                                                             size_t total_groups)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_groups)
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void hamming_volume_kernel(const u32 *__restri
     const int g = (int)(t - pix * gpp);
     const int x = (int)(pix % (size_t)w);
     const u32 cl = cens_left[pix];
-    const u32 *cr = cens_right + pix;
+    const u32 *cr = cens_right + (pix / (size_t)w) * (size_t)wpr + xoffr + x; // pix / w = row over all pairs
     u32 o[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {

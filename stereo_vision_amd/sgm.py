@@ -31,6 +31,7 @@ class StereoSGMParams:
     num_paths: int = 8
     device: int = 0
     max_batch: int = 1
+    flags: int = 0  # _lib.FLAG_MATERIALIZE keeps the C and S volumes in HBM like the reference
 
 
 SGMParams = StereoSGMParams  # sgm.h:18-23 has the same four ints
@@ -47,7 +48,7 @@ class Engine:
         self.lib = _lib.load()
         self.params = params
         p = SgmxParams(params.disp_range, params.window_sz, params.penalty1, params.penalty2, params.num_paths,
-                       params.device, params.max_batch, 0)
+                       params.device, params.max_batch, params.flags)
         h = C.c_void_p()
         rc = self.lib.sgmx_create(C.byref(p), C.byref(h))
         if rc != 0:

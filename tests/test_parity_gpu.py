@@ -62,16 +62,22 @@ CASES = [
     (27, 160, 256, 5, 15, 100, 8),
     (21, 90, 270, 5, 7, 60, 8),
     (19, 70, 512, 3, 5, 5000, 8),
+    (19, 70, 512, 3, 5, 255, 8),
     (12, 9, 16, 5, 0, 0, 8),
     (64, 7, 32, 3, 3, 7044, 8),
+    (64, 7, 32, 3, 200, 255, 4),
+    (9, 300, 128, 9, 3, 60, 8),
 ]
 
 
+@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
-def test_pipeline_stages_bit_exact(oracle, case):
+def test_pipeline_stages_bit_exact(oracle, case, flags):
+    """Every stage of both census formulations: the default one (C recomputed from the census
+    images, one byte per voxel and direction; used when P2 <= 255) and the materialised C/S one."""
     H, W, D, wsz, P1, P2, paths = case
     left, right = synth_pair(H * 1000 + W + D, H, W, min(D, W // 2))
-    e = make(disp_range=D, window_sz=wsz, penalty1=P1, penalty2=P2, num_paths=paths)
+    e = make(disp_range=D, window_sz=wsz, penalty1=P1, penalty2=P2, num_paths=paths, flags=flags)
     disp = e.compute(left, right)
     want = oracle.sgm_census(left, right, D, wsz, P1, P2, paths, taps=True)
     st = e.stages(H, W)
@@ -83,14 +89,15 @@ def test_pipeline_stages_bit_exact(oracle, case):
     assert np.array_equal(e.data_cost_image(H, W), oracle.data_cost_wta(want["C"], m))
 
 
-@pytest.mark.parametrize("shape", [(5, 5), (6, 40), (40, 6), (5, 300)])
-def test_degenerate_shapes(oracle, shape):
-    """Cropped images of 1 x 1, one row, one column; D larger than the width."""
+@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
+@pytest.mark.parametrize("shape", [(5, 5), (6, 40), (40, 6), (5, 300), (6, 6), (7, 5), (5, 7)])
+def test_degenerate_shapes(oracle, shape, flags):
+    """Cropped images of 1 x 1, one row, one column, 2 x 2; D larger than the width."""
     H, W = shape
     rng = np.random.default_rng(H * 7 + W)
     left = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
     right = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
-    e = make(disp_range=64, window_sz=5)
+    e = make(disp_range=64, window_sz=5, flags=flags)
     assert np.array_equal(e.compute(left, right), oracle.sgm_census(left, right, 64, 5, 3, 60, 8))
 
 
@@ -124,9 +131,10 @@ def test_kitti_golden_full_size(oracle, kitti):
         assert oracle.fnv_u16(disp) == fnv
 
 
-def test_kitti_stages_vs_oracle(oracle, kitti):
+@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
+def test_kitti_stages_vs_oracle(oracle, kitti, flags):
     left, right = kitti
-    e = make(disp_range=128, window_sz=5)
+    e = make(disp_range=128, window_sz=5, flags=flags)
     disp = e.compute(left, right)
     want = oracle.sgm_census(left, right, 128, 5, 3, 60, 8, taps=True)
     st = e.stages(*left.shape)
