@@ -5,7 +5,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgmx.so")
+LIB_PATH = os.environ.get("SGMX_LIB") or os.path.join(_HERE, "libsgmx.so")  # SGMX_LIB: experiment builds
 
 SGMX_OK = 0
 FLAG_MATERIALIZE = 1  # SGMX_FLAG_MATERIALIZE

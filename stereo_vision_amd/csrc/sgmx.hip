@@ -37,7 +37,8 @@ struct sgmx_ctx {
     int W = 0, H = 0;          // census: full image; float: volume size
     int w = 0, h = 0, m = 0;   // cropped
     int mode = 0;              // 0 none, 1 census, 2 float
-    bool fast = false;         // census path without C / S volumes (sgmx_kernels_v2.hpp): P2 <= 255
+    bool fast = false;         // census path without C / S volumes (sgmx_kernels_v2.hpp): P2 <= 255, D <= 256
+    int RP = 4, DpF = 128;     // fast path: packed pairs per lane, padded disparity count 32 * RP
     int wp = 0;                // row pitch of the padded right census image (fast path)
     int last_n = 0;            // pairs in the last launch group
 
@@ -109,8 +110,10 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
     c->bytes_C = npix * c->Dp * esz_c;
     c->bytes_S = npix * c->Dp * esz_s;
     c->bytes_BL = (size_t)(2 * w + 2 * h) * c->Dp * esz_s;
+    if (mode == 1 && c->fast)
+        c->bytes_BL = (size_t)(2 * w + 2 * h) * c->DpF * 2;
     const bool fast = mode == 1 && c->fast;
-    c->wp = fast ? w + c->Dp : w;
+    c->wp = fast ? w + c->DpF : w;
     if (mode == 1) {
         HIPCHK(c, hipMalloc((void **)&c->d_left, nfull * B));
         HIPCHK(c, hipMalloc((void **)&c->d_right, nfull * B));
@@ -119,7 +122,7 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
         HIPCHK(c, hipMemset(c->d_cr, 0, (size_t)c->wp * h * 4 * B)); // the padding columns are never written again
     }
     if (fast) {
-        c->bytes_E = npix * c->Dp;
+        c->bytes_E = npix * c->DpF;
         HIPCHK(c, hipMalloc((void **)&c->d_E, c->bytes_E * B * c->prm.num_paths));
         HIPCHK(c, hipMalloc((void **)&c->d_SB, c->bytes_BL * B));
     } else {
@@ -263,20 +266,23 @@ int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t s
     return SGMX_OK;
 }
 
-template <int R> void launch_agg2(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
-                                  uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a)
+#ifndef SGMX_EXP_PF
+#define SGMX_EXP_PF 4
+#endif
+template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
+                                   uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a)
 {
-    constexpr int PF = 8;
+    constexpr int PF = RP == 8 ? 2 : SGMX_EXP_PF;
     if (first) {
         if (pad)
-            hipLaunchKernelGGL((aggregate2_kernel<R, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+            hipLaunchKernelGGL((aggregate3_kernel<RP, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
         else
-            hipLaunchKernelGGL((aggregate2_kernel<R, true, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+            hipLaunchKernelGGL((aggregate3_kernel<RP, true, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
     } else {
         if (pad)
-            hipLaunchKernelGGL((aggregate2_kernel<R, false, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+            hipLaunchKernelGGL((aggregate3_kernel<RP, false, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
         else
-            hipLaunchKernelGGL((aggregate2_kernel<R, false, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+            hipLaunchKernelGGL((aggregate3_kernel<RP, false, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
     }
 }
 
@@ -296,7 +302,7 @@ SumArgs sum_args(const sgmx_ctx *c)
     return a;
 }
 
-size_t wta2_lds_bytes(const sgmx_ctx *c) { return (size_t)4 * (64 / (8 * c->R)) * (c->Dp / 2) * 4 + (size_t)c->w * 16; }
+size_t wta3_lds_bytes(const sgmx_ctx *c) { return (size_t)16 * (c->DpF / 2) * 4 + (size_t)c->w * 16; }
 
 // Fast census path: the ordered direction sweeps writing byte volumes, then the fused
 // sum + WTA / LR / subpixel kernel and the median.
@@ -305,7 +311,7 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
     const int np = c->prm.num_paths;
     HIPCHK(c, hipMemsetAsync(c->d_BL, 0, c->bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
     HIPCHK(c, hipMemsetAsync(c->d_SB, 0, c->bytes_BL * n, st));
-    const bool pad = c->prm.disp_range != c->Dp;
+    const bool pad = c->prm.disp_range != c->DpF;
     for (int k = 0; k < np; k++) {
         Agg2Args a;
         a.w = c->w;
@@ -317,32 +323,36 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
         a.P1 = c->prm.penalty1;
         a.P2 = c->prm.penalty2;
         a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
-        const dim3 grid((a.npaths + 3) / 4, n);
+        const dim3 grid((a.npaths + 15) / 16, n); // 4 waves x 4 paths per workgroup
         uint8_t *Ek = c->d_E + (size_t)k * c->bytes_E * c->prm.max_batch;
         ProfScope ps(c, SGMX_K_AGGREGATE, st);
-        if (c->R == 1)
-            launch_agg2<1>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
-        else if (c->R == 2)
-            launch_agg2<2>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+        if (c->RP == 1)
+            launch_agg3<1>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+        else if (c->RP == 2)
+            launch_agg3<2>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+        else if (c->RP == 4)
+            launch_agg3<4>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
         else
-            launch_agg2<4>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<8>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
         HIPCHK(c, hipGetLastError());
     }
     {
         ProfScope ps(c, SGMX_K_WTA, st);
         const SumArgs sa = sum_args(c);
-        const size_t lds = wta2_lds_bytes(c);
+        const size_t lds = wta3_lds_bytes(c);
         const dim3 grid(c->h, n);
-        if (lds > 64 * 1024) { // beyond the default dynamic-LDS limit
-            const void *fn = c->R == 1 ? (const void *)wta2_kernel<1> : c->R == 2 ? (const void *)wta2_kernel<2> : (const void *)wta2_kernel<4>;
+        const void *fn = c->RP == 1 ? (const void *)wta3_kernel<1> : c->RP == 2 ? (const void *)wta3_kernel<2>
+                       : c->RP == 4 ? (const void *)wta3_kernel<4> : (const void *)wta3_kernel<8>;
+        if (lds > 64 * 1024) // beyond the default dynamic-LDS limit
             HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        if (c->R == 1)
-            hipLaunchKernelGGL(wta2_kernel<1>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
-        else if (c->R == 2)
-            hipLaunchKernelGGL(wta2_kernel<2>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+        if (c->RP == 1)
+            hipLaunchKernelGGL(wta3_kernel<1>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+        else if (c->RP == 2)
+            hipLaunchKernelGGL(wta3_kernel<2>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+        else if (c->RP == 4)
+            hipLaunchKernelGGL(wta3_kernel<4>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
         else
-            hipLaunchKernelGGL(wta2_kernel<4>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+            hipLaunchKernelGGL(wta3_kernel<8>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
         HIPCHK(c, hipGetLastError());
     }
     {
@@ -358,10 +368,10 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
 int materialize_cost(sgmx_ctx *c, int index, uint8_t *d_dst, hipStream_t st)
 {
     const size_t npix = (size_t)c->w * c->h;
-    const size_t groups = npix * (c->Dp / 16);
+    const size_t groups = npix * (c->DpF / 16);
     hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
-                       c->d_cl + (size_t)index * npix, c->d_cr + (size_t)index * c->wp * c->h, c->wp, c->Dp, c->w, c->h,
-                       c->prm.disp_range, c->Dp, d_dst, groups);
+                       c->d_cl + (size_t)index * npix, c->d_cr + (size_t)index * c->wp * c->h, c->wp, c->DpF, c->w, c->h,
+                       c->prm.disp_range, c->DpF, d_dst, groups);
     HIPCHK(c, hipGetLastError());
     return SGMX_OK;
 }
@@ -373,7 +383,7 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
     {
         ProfScope ps(c, SGMX_K_CENSUS, st);
         hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 2 * n), dim3(256), 0, st, dL, dR, n, W, H,
-                           c->prm.window_sz, c->d_cl, c->d_cr, c->wp, c->fast ? c->Dp : 0);
+                           c->prm.window_sz, c->d_cl, c->d_cr, c->wp, c->fast ? c->DpF : 0);
         HIPCHK(c, hipGetLastError());
     }
     if (c->fast) {
@@ -455,7 +465,9 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->prm = p;
     c->R = p.disp_range <= 128 ? 1 : (p.disp_range <= 256 ? 2 : 4);
     c->Dp = 128 * c->R;
-    c->fast = p.penalty2 <= 255 && !(p.flags & SGMX_FLAG_MATERIALIZE);
+    c->fast = p.penalty2 <= 255 && p.disp_range <= 256 && !(p.flags & SGMX_FLAG_MATERIALIZE);
+    c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : 8));
+    c->DpF = 32 * c->RP;
     if (hipSetDevice(p.device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
         delete c;
         return fail(nullptr, SGMX_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
@@ -733,7 +745,7 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
         return fail(c, SGMX_ERR_INVALID_ARG, "pair index outside the last launch group");
     HIPCHK(c, hipSetDevice(c->prm.device));
     HIPCHK(c, hipDeviceSynchronize());
-    const int D = c->prm.disp_range, Dp = c->Dp;
+    const int D = c->prm.disp_range, Dp = (mode == 1 && c->fast) ? c->DpF : c->Dp;
     const size_t npix = (size_t)c->w * c->h, tot = npix * D;
     const size_t esz_c = mode == 1 ? 1 : 4, esz_s = mode == 1 ? 2 : 4;
     void *tmp = nullptr;
@@ -765,14 +777,16 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
     if (S && e == hipSuccess) {
         if (fast) {
             const SumArgs sa = sum_args(c);
-            const size_t thr = npix * (size_t)(8 * c->R);
+            const size_t thr = npix * 16;
             const dim3 grid((unsigned)((thr + 255) / 256));
-            if (c->R == 1)
+            if (c->RP == 1)
                 hipLaunchKernelGGL(sums_tap_kernel<1>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
-            else if (c->R == 2)
+            else if (c->RP == 2)
                 hipLaunchKernelGGL(sums_tap_kernel<2>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
-            else
+            else if (c->RP == 4)
                 hipLaunchKernelGGL(sums_tap_kernel<4>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
+            else
+                hipLaunchKernelGGL(sums_tap_kernel<8>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
         } else if (mode == 1)
             hipLaunchKernelGGL(repitch_kernel<uint16_t>, dim3(nb), dim3(256), 0, st,
                                (const uint16_t *)((const uint8_t *)c->d_S + index * c->bytes_S), Dp, (uint16_t *)tmp, D,
@@ -821,7 +835,7 @@ int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
     const uint8_t *src = (const uint8_t *)c->d_C + index * c->bytes_C;
     uint8_t *vol = nullptr;
     if (c->fast) {
-        if (hipMalloc((void **)&vol, (size_t)c->w * c->h * c->Dp) != hipSuccess || materialize_cost(c, index, vol, st) != SGMX_OK) {
+        if (hipMalloc((void **)&vol, (size_t)c->w * c->h * c->DpF) != hipSuccess || materialize_cost(c, index, vol, st) != SGMX_OK) {
             (void)hipFree(d_o);
             (void)hipFree(vol);
             return fail(c, SGMX_ERR_OOM, "data-cost WTA tap: cannot rebuild the data-cost volume");
@@ -829,7 +843,7 @@ int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
         src = vol;
     }
     hipLaunchKernelGGL(data_cost_wta_kernel, dim3((c->w + 255) / 256, c->h), dim3(256), 0, st, src, c->w, c->h,
-                       c->prm.disp_range, c->Dp, c->m, d_o);
+                       c->prm.disp_range, c->fast ? c->DpF : c->Dp, c->m, d_o);
     if (e == hipSuccess)
         e = hipMemcpyAsync(out, d_o, nfull, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);

@@ -1,5 +1,5 @@
-// sgmx_kernels_v2.hpp -- the census/Hamming fast path (P2 <= 255): no data-cost volume and
-// no summed-cost volume in HBM.
+// sgmx_kernels_v2.hpp -- the census/Hamming fast path (P2 <= 255, D <= 256): no data-cost
+// volume and no summed-cost volume in HBM.
 //
 //   * The Hamming data cost C(p,d) = popcount(censL[p] ^ censR[p-d]) (stereo_sgm.cc:75-101,
 //     stereo_costs.h:120-132) is recomputed inside the sweeps from the two census images, which
@@ -7,22 +7,38 @@
 //   * aggregate_path (stereo_sgm.h:119-147) gives L = C + E with
 //         E = min(prior[d], prior[d+-1] + P1, m + P2) - m,   0 <= E <= P2,
 //     so with P2 <= 255 every direction stores only E as ONE byte per voxel into its own volume
-//     (write-only, 128-byte lines) instead of read-modify-writing a uint16 sum (sum_costs,
-//     stereo_sgm.h:105-117).  On start pixels L = L_{k-1} + C (stereo_sgm.cc:201,218,236,254) can be
-//     larger: they are image-border pixels, their E byte is 0 and L_{k-1} goes into the small
-//     border accumulator SB (uint16 ring).  The final kernel rebuilds
+//     (write-only) instead of read-modify-writing a uint16 sum (sum_costs, stereo_sgm.h:105-117).
+//     On start pixels L = L_{k-1} + C (stereo_sgm.cc:201,218,236,254) can be larger: they are
+//     image-border pixels, their E byte is 0 and L_{k-1} goes into the small border accumulator SB
+//     (uint16 ring).  The final kernel rebuilds
 //         S(p,d) = N C(p,d) + sum_k E_k(p,d) (+ SB on border pixels)
 //     exactly (integers), and does WTA / right-view argmin / LR check / subpixel on it.
 //   HBM bytes per voxel: N (E writes) + N (E reads) = 16 at N = 8, against 41 for the materialised
-//   C + S formulation that the algorithmic-byte model counts.
+//   C + S formulation that the algorithmic-byte model counts.  With that the sweeps are bound by
+//   VALU issue (4 cycles per wave64 instruction), so the mapping minimises instructions per pixel:
 //
-// Census layout for this path: left uint32 [h][w]; right uint32 [h][wp], wp = Dp + w, pixel x in
-// column Dp + x, so that the 2R values censR[x-d] of a lane are one contiguous, in-row load for
-// every x >= 0 (columns < Dp are padding; costs with d > x are forced to 255, stereo_sgm.cc:43).
+// Lane mapping ("16 x RP x 2"): a pixel's Dp = 32 RP disparities live in ONE 16-lane DPP row; a
+// wave carries 4 pixels -- 4 different paths of the same direction, walked in lock step.  Lane q
+// of a row holds RP packed uint16 pairs, register j = ( d = RP q + j , d = Dp/2 + RP q + j ).
+//   - d-1 / d+1 of register j are registers j-1 / j+1 of the same lane (no shuffles); only
+//     register 0 / RP-1 need the neighbour lane: one row rotate each plus a fix-up of the lane
+//     where the low half wraps into the high half.
+//   - min over d is RP-1 packed mins, a half swap, and 4 row-rotate DPP mins that leave the
+//     minimum in every lane of the row (both halves), no scalar round trip.
+//
+// Memory layouts private to this path (d_lo = RP q + j, d_hi = Dp/2 + RP q + j):
+//   census left  uint32 [h][w];  census right uint32 [h][wp], wp = Dp + w, pixel x in column Dp + x
+//     (so the RP words censR[x-d] of a lane window are one contiguous in-row load for every x >= 0;
+//      costs with d > x are forced to 255, stereo_sgm.cc:43)
+//   E_k   uint8  [h][w][Dp]     byte 2 (RP q + j) = E(d_lo), byte 2 (RP q + j) + 1 = E(d_hi)
+//   BL/SB uint16 [2w+2h][Dp]    uint32 (RP q + j) = ( value(d_lo) , value(d_hi) << 16 )
 #pragma once
 #include "sgmx_kernels.hpp"
 
 namespace sgmx {
+
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 struct Agg2Args {
     int w, h, D, wp;   // cropped size, real disparity count, census-right row pitch
@@ -31,205 +47,311 @@ struct Agg2Args {
     int npaths;
 };
 
-// 2R census words of one lane: v[i] = censR[x - d0 - (2R-1) + i], i.e. disparity d0 + 2R-1 - i.
-template <int R> struct CensRaw { u32 v[2 * R]; };
+template <bool B> struct BoolC { static constexpr bool value = B; };
 
-template <int R> __device__ __forceinline__ CensRaw<R> load_cens(const u32 *p)
+// row_ror:N -- lane q of every 16-lane row reads lane (q - N) mod 16 of its row
+template <int N> __device__ __forceinline__ u32 row_ror(u32 v)
 {
-    CensRaw<R> r;
-    __builtin_memcpy(r.v, p, 8 * R); // 4-byte aligned multi-dword load
-    return r;
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x120 + N, 0xF, 0xF, true);
+}
+// Minimum over the 16 lanes of a row, left in every lane.  0xFFFFFFFF as `old` is the identity of
+// umin, which lets the compiler fold each step into one v_min_u32_dpp.
+__device__ __forceinline__ u32 row_min_u32(u32 x)
+{
+    x = min(x, dpp<0x121>(0xFFFFFFFFu, x));
+    x = min(x, dpp<0x122>(0xFFFFFFFFu, x));
+    x = min(x, dpp<0x124>(0xFFFFFFFFu, x));
+    x = min(x, dpp<0x128>(0xFFFFFFFFu, x));
+    return x;
 }
 
-template <int R, bool MASK>
-__device__ __forceinline__ void cost_from_census(const CensRaw<R> &raw, u32 cl, int x, int d0, u32 (&c)[R])
+// RP consecutive census words through a buffer descriptor (4-byte aligned)
+template <int RP> __device__ __forceinline__ void buf_load_win(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[RP]);
+template <> __device__ __forceinline__ void buf_load_win<1>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[1])
 {
+    o[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void buf_load_win<2>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[2])
+{
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    o[0] = t.x; o[1] = t.y;
+}
+template <> __device__ __forceinline__ void buf_load_win<4>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[4])
+{
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+template <> __device__ __forceinline__ void buf_load_win<8>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[8])
+{
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; o[4] = u.x; o[5] = u.y; o[6] = u.z; o[7] = u.w;
+}
+
+// RP packed pairs (each half <= 255) -> 2 RP bytes [lo0, hi0, lo1, hi1, ...]
+template <int RP> __device__ __forceinline__ void buf_store_e(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[RP]);
+template <> __device__ __forceinline__ void buf_store_e<1>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[1])
+{
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)__builtin_amdgcn_perm(0u, e[0], 0x0c0c0200u), rs, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void buf_store_e<2>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[2])
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(e[1], e[0], 0x06040200u), rs, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void buf_store_e<4>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[4])
+{
+    u32x2 v;
+    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u);
+    v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void buf_store_e<8>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[8])
+{
+    u32x4 v;
+    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u);
+    v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
+    v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u);
+    v.w = __builtin_amdgcn_perm(e[7], e[6], 0x06040200u);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0);
+}
+
+// Hamming costs of a lane: wl[i] = censR[x - RP q - (RP-1) + i] (register j = RP-1-i, low half),
+// wh[i] the same Dp/2 columns further left (high half).  tl = x - RP q: with MASK the halves
+// whose disparity exceeds x become 255 (cost <= 32, so OR-ing 0xFF works).
+template <int RP, bool MASK>
+__device__ __forceinline__ void cost_from_census(const u32 (&wl)[RP], const u32 (&wh)[RP], u32 cl, int tl, u32 (&c)[RP])
+{
+    constexpr int HALF = 16 * RP;
 #pragma unroll
-    for (int j = 0; j < R; j++) {
-        const u32 lo = (u32)__builtin_popcount(raw.v[2 * R - 1 - 2 * j] ^ cl);
-        const u32 hi = (u32)__builtin_popcount(raw.v[2 * R - 2 - 2 * j] ^ cl);
+    for (int j = 0; j < RP; j++) {
+        const u32 lo = (u32)__builtin_popcount(wl[RP - 1 - j] ^ cl);
+        const u32 hi = (u32)__builtin_popcount(wh[RP - 1 - j] ^ cl);
         c[j] = lo | (hi << 16);
-        if (MASK) { // d > x: no such pixel in the right view -> 255 (cost <= 32, so OR works)
-            const int d = d0 + 2 * j;
-            c[j] |= (d > x ? 0xFFu : 0u) | (d + 1 > x ? 0xFF0000u : 0u);
-        }
+        if (MASK)
+            c[j] |= (j > tl ? 0xFFu : 0u) | (j > tl - HALF ? 0xFF0000u : 0u);
     }
 }
 
-// R packed uint16 pairs (each value <= 255) -> 2R bytes
-template <int R> __device__ __forceinline__ void store_e(uint8_t *p, const u32 (&e)[R]);
-template <> __device__ __forceinline__ void store_e<1>(uint8_t *p, const u32 (&e)[1])
+// Per-lane path geometry (each 16-lane row walks its own path); see path_geometry.
+struct LaneGeom {
+    int x0, y0, len;
+    bool edge;
+};
+__device__ __forceinline__ LaneGeom lane_geometry(int p, int w, int h, int dx, int dy)
 {
-    *reinterpret_cast<unsigned short *>(p) = (unsigned short)__builtin_amdgcn_perm(0u, e[0], 0x0c0c0200u);
-}
-template <> __device__ __forceinline__ void store_e<2>(uint8_t *p, const u32 (&e)[2])
-{
-    *reinterpret_cast<u32 *>(p) = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u);
-}
-template <> __device__ __forceinline__ void store_e<4>(uint8_t *p, const u32 (&e)[4])
-{
-    *reinterpret_cast<uint2 *>(p) =
-        make_uint2(__builtin_amdgcn_perm(e[1], e[0], 0x06040200u), __builtin_amdgcn_perm(e[3], e[2], 0x06040200u));
+    const int xe = dx > 0 ? 0 : w - 1;
+    const int ye = dy > 0 ? 0 : h - 1;
+    const bool on_col = (dy == 0) || (dx != 0 && p < h);
+    const int q = p - h;
+    LaneGeom g;
+    g.x0 = on_col ? xe : (dx == 0 ? p : (dx > 0 ? q + 1 : q));
+    g.y0 = on_col ? p : ye;
+    const int sx = dx == 0 ? 0x7fffffff : (dx > 0 ? w - g.x0 : g.x0 + 1);
+    const int sy = dy == 0 ? 0x7fffffff : (dy > 0 ? h - g.y0 : g.y0 + 1);
+    g.len = sx < sy ? sx : sy;
+    g.edge = (dy == 0 && (g.y0 == 0 || g.y0 == h - 1)) || (dx == 0 && (g.x0 == 0 || g.x0 == w - 1));
+    return g;
 }
 
 // ---------------------------------------------------------------------------
-// K3' one direction sweep.  One wave per path, disparities across lanes (2R per lane),
-// stereo_sgm.cc:191-268 + stereo_sgm.h:119-147.  cl/cr: census images of the launch group,
-// E: this direction's byte volume [pairs][h][w][Dp], BL: border ring of L_{k-1} (in) / L_k (out),
-// SB: border accumulator of the start-pixel carry.
+// K3' one direction sweep (stereo_sgm.cc:191-268 + stereo_sgm.h:119-147), 4 paths per wave.
+// cl/cr: census images of the launch group, E: this direction's byte volume, BL: border ring of
+// L_{k-1} (in) / L_k (out), SB: border accumulator of the start-pixel carry.
+//
+// Addressing costs no VALU: all 4 paths of a wave share the per-step byte stride, so each stream
+// is  base' + voffset(lane: start of its path + its window) + soffset(step),  with soffset walked by
+// one scalar add.  For a negative stride the walk runs downwards from T|s| (T = longest path - 1)
+// and base' = base - T|s|, so soffset never goes negative; the descriptors are unbounded.
 // ---------------------------------------------------------------------------
-template <int R, bool FIRST, bool HAS_PAD, int PF>
-__global__ __launch_bounds__(256) void aggregate2_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
+template <int RP, bool FIRST, bool HAS_PAD, int PF>
+__global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
                                                          uint8_t *__restrict__ E, uint16_t *__restrict__ BL,
                                                          uint16_t *__restrict__ SB, const Agg2Args a)
 {
-    constexpr int Dp = 128 * R;
+    constexpr int Dp = 32 * RP, HALF = 16 * RP;
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (p >= a.npaths)
+    const int q = lane & 15;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave * 4 >= a.npaths)
         return;
     const int w = a.w, h = a.h, wp = a.wp;
     const size_t npix = (size_t)w * h;
-    const int d0 = lane * (2 * R);           // this lane's first disparity
-    const unsigned loff = lane * (2 * R);    // byte offset into a pixel's E line / element offset into a ring line
-    const unsigned coff = Dp - d0 - 2 * R;   // element offset of this lane's census window relative to column x+1
-    const u32 *clf = cl + (size_t)blockIdx.y * npix;
-    const u32 *crf = cr + (size_t)blockIdx.y * (size_t)h * wp + 1;
-    uint8_t *Ef = E + (size_t)blockIdx.y * npix * Dp;
-    const size_t ring = (size_t)(2 * w + 2 * h) * Dp;
-    uint16_t *BLf = BL + (size_t)blockIdx.y * ring;
-    uint16_t *SBf = SB + (size_t)blockIdx.y * ring;
-
-    const PathGeom g = path_geometry(p, w, h, a.dx, a.dy);
+    // rows past the last path repeat it (same loads, same E bytes) with their ring stores disabled
+    const int praw = wave * 4 + (lane >> 4);
+    const bool valid = praw < a.npaths;
+    const LaneGeom g = lane_geometry(valid ? praw : a.npaths - 1, w, h, a.dx, a.dy);
     const int len = g.len;
-    const int pstride = a.dy * w + a.dx;   // pixels per step in the dense images
-    const int cstride = a.dy * wp + a.dx;  // elements per step in the padded census-right image
-    const int pix0 = g.y0 * w + g.x0;
-    const int cix0 = g.y0 * wp + g.x0;
+    int minlen = __builtin_amdgcn_readlane(len, 0), maxlen = minlen, minx = __builtin_amdgcn_readlane(g.x0, 0);
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        const int l = __builtin_amdgcn_readlane(len, 16 * r), x = __builtin_amdgcn_readlane(g.x0, 16 * r);
+        minlen = l < minlen ? l : minlen;
+        maxlen = l > maxlen ? l : maxlen;
+        minx = x < minx ? x : minx;
+    }
+    const bool any_edge = __builtin_amdgcn_readfirstlane((int)(__ballot(g.edge) != 0ull)) != 0;
+
+    // per-step byte strides and stream bases
+    const int sRi = (a.dy * wp + a.dx) * 4, sLi = (a.dy * w + a.dx) * 4, sEi = (a.dy * w + a.dx) * Dp;
+    const unsigned T = (unsigned)(maxlen - 1);
+    const unsigned soR0 = sRi < 0 ? T * (unsigned)(-sRi) : 0u, soL0 = sLi < 0 ? T * (unsigned)(-sLi) : 0u,
+                   soE0 = sEi < 0 ? T * (unsigned)(-sEi) : 0u;
+    const unsigned sR = (unsigned)sRi, sL = (unsigned)sLi, sE = (unsigned)sEi;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(cr + (size_t)blockIdx.y * (size_t)h * wp) - soR0), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(cl + (size_t)blockIdx.y * npix) - soL0), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsE =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(E + (size_t)blockIdx.y * npix * Dp) - soE0, 0, -1, 0x00020000);
+    // lane parts: start pixel of the lane's path + its window / line slice
+    const unsigned voR = (unsigned)((g.y0 * wp + Dp + g.x0 - RP * q - (RP - 1) - HALF) * 4); // high-half window; low = + HALF*4
+    const unsigned voL = (unsigned)((g.y0 * w + g.x0) * 4);
+    const unsigned voE = (unsigned)((g.y0 * w + g.x0) * Dp + 2 * RP * q);
+    const size_t ring = (size_t)(2 * w + 2 * h) * (Dp / 2); // uint32 units
+    u32 *BLf = reinterpret_cast<u32 *>(BL) + (size_t)blockIdx.y * ring + RP * q;
+    u32 *SBf = reinterpret_cast<u32 *>(SB) + (size_t)blockIdx.y * ring + RP * q;
 
     const u32 P1p = (u32)a.P1 * 0x10001u, P2p = (u32)a.P2 * 0x10001u;
-    u32 padfloor[R];
+    const int tl0 = g.x0 - RP * q; // x - RP q at step 0
+    u32 padfloor[RP];
 #pragma unroll
-    for (int j = 0; j < R; j++) {
-        const int d = d0 + 2 * j;
-        padfloor[j] = (d >= a.D ? INF16 : 0u) | (d + 1 >= a.D ? INF16 << 16 : 0u);
-    }
+    for (int j = 0; j < RP; j++)
+        padfloor[j] = (RP * q + j >= a.D ? INF16 : 0u) | (HALF + RP * q + j >= a.D ? INF16 << 16 : 0u);
 
-    // ---- step 0, the start pixel: L_k = L_{k-1} + C; its E byte is 0, the carry goes to SB
-    u32 prior[R];
+    // ---- step 0, the start pixels: L_k = L_{k-1} + C; their E bytes are 0, the carry goes to SB
+    u32 prior[RP];
     {
-        const size_t bo = (size_t)border_index(g.y0, g.x0, w, h) * Dp + loff;
-        u32 c[R];
-        cost_from_census<R, true>(load_cens<R>(crf + cix0 + coff), clf[pix0], g.x0, d0, c);
-        u32 zero[R];
+        u32 wl[RP], wh[RP], c[RP], zero[RP];
+        buf_load_win<RP>(rsR, voR + HALF * 4, soR0, wl);
+        buf_load_win<RP>(rsR, voR, soR0, wh);
+        const u32 clv = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0, 0);
+        cost_from_census<RP, true>(wl, wh, clv, tl0, c);
+        const size_t bo = (size_t)border_index(g.y0, g.x0, w, h) * (Dp / 2);
         if (FIRST) {
 #pragma unroll
-            for (int j = 0; j < R; j++)
+            for (int j = 0; j < RP; j++)
                 prior[j] = c[j];
         } else {
-            const SRaw<R> bl = load_s<R>(BLf + bo);
-            const SRaw<R> sb = load_s<R>(SBf + bo);
-            u32 sbn[R];
+            u32 bl[RP], sb[RP];
+            __builtin_memcpy(bl, BLf + bo, 4 * RP);
+            __builtin_memcpy(sb, SBf + bo, 4 * RP);
 #pragma unroll
-            for (int j = 0; j < R; j++) {
-                prior[j] = pk_add(bl.v[j], c[j]);
-                sbn[j] = pk_add(sb.v[j], bl.v[j]);
+            for (int j = 0; j < RP; j++) {
+                prior[j] = pk_add(bl[j], c[j]);
+                sb[j] = pk_add(sb[j], bl[j]);
             }
-            store_s<R>(SBf + bo, sbn);
+            if (valid)
+                __builtin_memcpy(SBf + bo, sb, 4 * RP);
         }
 #pragma unroll
-        for (int j = 0; j < R; j++) {
+        for (int j = 0; j < RP; j++) {
             if (HAS_PAD)
                 prior[j] = pk_max(prior[j], padfloor[j]);
             zero[j] = 0u;
         }
-        store_e<R>(Ef + (size_t)pix0 * Dp + loff, zero);
-        store_s<R>(BLf + bo, prior);
+        buf_store_e<RP>(rsE, voE, soE0, zero);
+        if (valid)
+            __builtin_memcpy(BLf + bo, prior, 4 * RP);
     }
-    if (len == 1)
+    if (maxlen == 1)
         return;
 
     // ---- steps 1 .. len-1; ring slot i holds a step t with (t-1) % PF == i
-    CensRaw<R> cq[PF];
-    u32 lq[PF];
+    u32 qwl[PF][RP], qwh[PF][RP], qcl[PF];
 #pragma unroll
-    for (int i = 0; i < PF; i++) {
-        const int t = 1 + i < len ? 1 + i : len - 1;
-        cq[i] = load_cens<R>(crf + (cix0 + t * cstride) + coff);
-        lq[i] = clf[pix0 + t * pstride];
-    }
-    const int xl = g.x0 + (len - 1) * a.dx, yl = g.y0 + (len - 1) * a.dy; // last pixel
-    uint16_t *bl_last = BLf + (size_t)border_index(yl, xl, w, h) * Dp;
-
-    int pix = pix0, cix = cix0, x = g.x0;
-    auto step = [&](int t, int i, bool prefetch) {
-        pix += pstride;
-        cix += cstride;
-        x += a.dx;
-        const CensRaw<R> raw = cq[i];
-        const u32 clv = lq[i];
-        if (prefetch) { // census words PF steps ahead
-            cq[i] = load_cens<R>(crf + (cix + PF * cstride) + coff);
-            lq[i] = clf[pix + PF * pstride];
+    for (int i = 0; i < PF; i++)
+        if (1 + i < len) {
+            buf_load_win<RP>(rsR, voR + HALF * 4, soR0 + (1 + i) * sR, qwl[i]);
+            buf_load_win<RP>(rsR, voR, soR0 + (1 + i) * sR, qwh[i]);
+            qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0 + (1 + i) * sL, 0);
         }
-        u32 c[R];
-        if (x < a.D - 1) // wave-uniform: only the first D-1 columns have d > x
-            cost_from_census<R, true>(raw, clv, x, d0, c);
-        else
-            cost_from_census<R, false>(raw, clv, x, d0, c);
+    u32 *bl_last = BLf + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
+    const bool lane0 = q == 0, lane15 = q == 15;
 
-        // stereo_sgm.h:129-146
-        const u32 left = dpp<0x138>(INF2, prior[R - 1]); // lane-1's top pair; lane 0 has no d-1
-        const u32 right = dpp<0x130>(INF2, prior[0]);    // lane+1's bottom pair; lane 63 has no d+1
+    unsigned soRp = soR0 + (1 + PF) * sR, soLp = soL0 + (1 + PF) * sL; // soffsets of the step PF ahead
+    unsigned soE = soE0;
+    auto step = [&](auto maskc, auto slowc, int t, int i) {
+        constexpr bool SLOW = decltype(slowc)::value;
+        soE += sE;
+        u32 wl[RP], wh[RP];
+#pragma unroll
+        for (int j = 0; j < RP; j++) {
+            wl[j] = qwl[i][j];
+            wh[j] = qwh[i][j];
+        }
+        const u32 clv = qcl[i];
+        if (!SLOW || t + PF < len) { // census words PF steps ahead (fast blocks: in range for every row)
+            buf_load_win<RP>(rsR, voR + HALF * 4, soRp, qwl[i]);
+            buf_load_win<RP>(rsR, voR, soRp, qwh[i]);
+            qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
+        }
+        soRp += sR;
+        soLp += sL;
+        u32 c[RP];
+        cost_from_census<RP, decltype(maskc)::value>(wl, wh, clv, tl0 + t * a.dx, c);
+
+        // stereo_sgm.h:129-146.  d-1 of register 0: lane q-1's top register; in lane 0 the low half has
+        // no d-1 and the high half continues lane 15's low half.  d+1 of register RP-1 mirrors that.
+        const u32 rdn = row_ror<1>(prior[RP - 1]);
+        const u32 rup = row_ror<15>(prior[0]);
+        const u32 prev0 = lane0 ? ((rdn << 16) | INF16) : rdn;
+        const u32 nextT = lane15 ? __builtin_amdgcn_alignbit(INF16, rup, 16) : rup;
         u32 mn = prior[0];
 #pragma unroll
-        for (int j = 1; j < R; j++)
+        for (int j = 1; j < RP; j++)
             mn = pk_min(mn, prior[j]);
-        const u32 m = wave_min_u32(min(mn & 0xFFFFu, mn >> 16));
-        const u32 mp = m * 0x10001u;
-        u32 e[R];
+        const u32 mp = row_min_u32(pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16))); // (m, m)
+        u32 e[RP];
 #pragma unroll
-        for (int j = 0; j < R; j++) {
-            const u32 prev = __builtin_amdgcn_alignbit(prior[j], j ? prior[j - 1] : left, 16);
-            const u32 next = __builtin_amdgcn_alignbit(j < R - 1 ? prior[j + 1] : right, prior[j], 16);
+        for (int j = 0; j < RP; j++) {
+            const u32 prev = j ? prior[j - 1] : prev0;
+            const u32 next = j < RP - 1 ? prior[j + 1] : nextT;
             const u32 A = pk_min(prior[j], pk_add(pk_min(prev, next), P1p));
             e[j] = pk_min(pk_sub(A, mp), P2p);
         }
 #pragma unroll
-        for (int j = 0; j < R; j++) {
+        for (int j = 0; j < RP; j++) {
             prior[j] = pk_add(e[j], c[j]);
             if (HAS_PAD)
                 prior[j] = pk_max(prior[j], padfloor[j]);
         }
-        store_e<R>(Ef + (size_t)pix * Dp + loff, e);
-        if (g.edge) { // path along an image edge: every pixel feeds a later direction's start
-            const int y = g.y0 + t * a.dy;
-            store_s<R>(BLf + (size_t)border_index(y, x, w, h) * Dp + loff, prior);
-        } else if (t == len - 1) {
-            store_s<R>(bl_last + loff, prior);
+        if (!SLOW) {
+            buf_store_e<RP>(rsE, voE, soE, e);
+        } else if (t < len) {
+            buf_store_e<RP>(rsE, voE, soE, e);
+            if (valid) {
+                if (g.edge) // path along an image edge: every pixel feeds a later direction's start
+                    __builtin_memcpy(BLf + (size_t)border_index(g.y0 + t * a.dy, g.x0 + t * a.dx, w, h) * (Dp / 2), prior, 4 * RP);
+                else if (t == len - 1)
+                    __builtin_memcpy(bl_last, prior, 4 * RP);
+            }
         }
     };
 
-    int t = 1;
-    for (; t + 2 * PF <= len; t += PF) { // every prefetch target t+i+PF <= len-1
+    for (int t = 1; t < maxlen; t += PF) {
+        if (!any_edge && t + 2 * PF <= minlen) { // every row: steps t..t+PF-1 and their prefetch targets exist, none is last
+            const int xa = minx + t * a.dx, xb = minx + (t + PF - 1) * a.dx;
+            if ((xa < xb ? xa : xb) < a.D - 1) { // some d > x in this block: costs need the 255 mask
 #pragma unroll
-        for (int i = 0; i < PF; i++)
-            step(t + i, i, true);
+                for (int i = 0; i < PF; i++)
+                    step(BoolC<true>(), BoolC<false>(), t + i, i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PF; i++)
+                    step(BoolC<false>(), BoolC<false>(), t + i, i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PF; i++)
+                if (t + i < maxlen)
+                    step(BoolC<true>(), BoolC<true>(), t + i, i);
+        }
     }
-#pragma unroll
-    for (int i = 0; i < PF; i++)
-        if (t + i < len)
-            step(t + i, i, t + i + PF < len);
-    t += PF;
-#pragma unroll
-    for (int i = 0; i < PF; i++)
-        if (t + i < len)
-            step(t + i, i, false);
 }
 
 // ---------------------------------------------------------------------------
-// S(p, 16g .. 16g+15) of one pixel as 8 packed uint16 pairs, rebuilt from the census images, the
-// N byte volumes and the border accumulator.  16 disparities per lane, 8R lanes per pixel.
+// S(p,.) of one pixel in the lane layout above (RP packed pairs per lane, 16 lanes per pixel),
+// rebuilt from the census images, the N byte volumes and the border accumulator.
 // ---------------------------------------------------------------------------
 struct SumArgs {
     const u32 *cl, *cr;
@@ -239,65 +361,90 @@ struct SumArgs {
     int w, h, D, wp, N;
 };
 
-template <int R>
-__device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, int x, int g, u32 (&S)[8])
+template <int RP> __device__ __forceinline__ void load_e_pairs(const uint8_t *p, u32 (&o)[RP]);
+template <> __device__ __forceinline__ void load_e_pairs<1>(const uint8_t *p, u32 (&o)[1])
 {
-    constexpr int Dp = 128 * R;
+    o[0] = __builtin_amdgcn_perm(0u, (u32) * reinterpret_cast<const unsigned short *>(p), 0x0c010c00u);
+}
+template <> __device__ __forceinline__ void load_e_pairs<2>(const uint8_t *p, u32 (&o)[2])
+{
+    const u32 v = *reinterpret_cast<const u32 *>(p);
+    o[0] = __builtin_amdgcn_perm(0u, v, 0x0c010c00u);
+    o[1] = __builtin_amdgcn_perm(0u, v, 0x0c030c02u);
+}
+template <> __device__ __forceinline__ void load_e_pairs<4>(const uint8_t *p, u32 (&o)[4])
+{
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    o[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u);
+    o[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
+    o[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u);
+    o[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
+}
+template <> __device__ __forceinline__ void load_e_pairs<8>(const uint8_t *p, u32 (&o)[8])
+{
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    const u32 d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        o[2 * k] = __builtin_amdgcn_perm(0u, d[k], 0x0c010c00u);
+        o[2 * k + 1] = __builtin_amdgcn_perm(0u, d[k], 0x0c030c02u);
+    }
+}
+
+template <int RP>
+__device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, int x, int q, u32 (&S)[RP])
+{
+    constexpr int Dp = 32 * RP, HALF = 16 * RP;
     const size_t pix = ((size_t)pair * a.h + y) * a.w + x;
     const u32 clv = a.cl[pix];
-    u32 r[16]; // r[i] = censR[x - 16g - 15 + i]  <->  d = 16g + 15 - i
-    __builtin_memcpy(r, a.cr + ((size_t)pair * a.h + y) * a.wp + (Dp + x - 16 * g - 15), 64);
-    const uint8_t *ep = a.E + pix * Dp + 16 * g;
-    uint4 ev[8];
+    u32 wl[RP], wh[RP];
+    const u32 *win = a.cr + ((size_t)pair * a.h + y) * a.wp + (Dp + x - RP * q - (RP - 1));
+    __builtin_memcpy(wl, win, 4 * RP);
+    __builtin_memcpy(wh, win - HALF, 4 * RP);
+    const uint8_t *ep = a.E + pix * Dp + 2 * RP * q;
+    u32 ev[8][RP];
 #pragma unroll
     for (int k = 0; k < 8; k++)
         if (k < a.N)
-            ev[k] = *reinterpret_cast<const uint4 *>(ep + (size_t)k * a.estride);
+            load_e_pairs<RP>(ep + (size_t)k * a.estride, ev[k]);
+    u32 c[RP];
+    cost_from_census<RP, true>(wl, wh, clv, x - RP * q, c);
     const int sh = a.N == 8 ? 3 : 2;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int d = 16 * g + 2 * q;
-        u32 lo = (u32)__builtin_popcount(r[15 - 2 * q] ^ clv);
-        u32 hi = (u32)__builtin_popcount(r[14 - 2 * q] ^ clv);
-        lo = d > x ? 255u : lo;
-        hi = d + 1 > x ? 255u : hi;
-        S[q] = (lo | (hi << 16)) << sh; // N * C
-    }
+    for (int j = 0; j < RP; j++)
+        S[j] = c[j] << sh; // N * C
 #pragma unroll
     for (int k = 0; k < 8; k++)
         if (k < a.N) {
-            const u32 e4[4] = {ev[k].x, ev[k].y, ev[k].z, ev[k].w};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                S[2 * q] = pk_add(S[2 * q], __builtin_amdgcn_perm(0u, e4[q], 0x0c010c00u));
-                S[2 * q + 1] = pk_add(S[2 * q + 1], __builtin_amdgcn_perm(0u, e4[q], 0x0c030c02u));
-            }
+            for (int j = 0; j < RP; j++)
+                S[j] = pk_add(S[j], ev[k][j]);
         }
     if (y == 0 || y == a.h - 1 || x == 0 || x == a.w - 1) {
-        const uint16_t *sp = a.SB + ((size_t)pair * (2 * a.w + 2 * a.h) + border_index(y, x, a.w, a.h)) * Dp + 16 * g;
-        const uint4 s0 = *reinterpret_cast<const uint4 *>(sp), s1 = *reinterpret_cast<const uint4 *>(sp + 8);
-        S[0] = pk_add(S[0], s0.x); S[1] = pk_add(S[1], s0.y); S[2] = pk_add(S[2], s0.z); S[3] = pk_add(S[3], s0.w);
-        S[4] = pk_add(S[4], s1.x); S[5] = pk_add(S[5], s1.y); S[6] = pk_add(S[6], s1.z); S[7] = pk_add(S[7], s1.w);
+        u32 sb[RP];
+        __builtin_memcpy(sb, reinterpret_cast<const u32 *>(a.SB) +
+                                 ((size_t)pair * (2 * a.w + 2 * a.h) + border_index(y, x, a.w, a.h)) * (Dp / 2) + RP * q,
+                         4 * RP);
+#pragma unroll
+        for (int j = 0; j < RP; j++)
+            S[j] = pk_add(S[j], sb[j]);
     }
 }
 
 // ---------------------------------------------------------------------------
 // K4+K5' WTA, right-view argmin, LR check, subpixel (stereo_sgm.h:209-241, 275-317) on the
-// rebuilt S.  One workgroup per image row; a wave handles 8/R pixels at a time, 16 disparities
-// per lane.  Right view: LDS atomicMin of (cost << 16 | d) keys into slot x-d, i.e. the
-// reference's diagonal scan S[y][xr+i][i] regrouped by xr; the smaller d wins ties like its
-// strict '<' scan.
+// rebuilt S.  One workgroup per image row; a wave handles 4 pixels at a time (one per DPP row).
+// Right view: LDS atomicMin of (cost << 16 | d) keys into slot x-d, i.e. the reference's diagonal
+// scan S[y][xr+i][i] regrouped by xr; the smaller d wins ties like its strict '<' scan.
 // ---------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(256) void wta2_kernel(const SumArgs a, int m, uint16_t *__restrict__ raw)
+template <int RP>
+__global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint16_t *__restrict__ raw)
 {
-    constexpr int Dp = 128 * R;
-    constexpr int LPP = 8 * R;    // lanes per pixel
-    constexpr int PPW = 64 / LPP; // pixels per wave
+    constexpr int Dp = 32 * RP, HALF = 16 * RP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = a.w, h = a.h, D = a.D;
-    u32 *tile = reinterpret_cast<u32 *>(smem);       // [4 waves][PPW][Dp/2] packed S of the pixels in flight
-    u32 *rkey = tile + 4 * PPW * (Dp / 2);           // [w] right-view best key
+    u32 *tile = reinterpret_cast<u32 *>(smem);       // [16 pixels in flight][Dp/2] packed S
+    u32 *rkey = tile + 16 * (Dp / 2);                // [w] right-view best key
     u32 *lkey = rkey + w;                            // [w] left-view best key
     u32 *s3a = lkey + w;                             // [w] S[d-1] | S[d] << 16 at the left winner
     u32 *s3b = s3a + w;                              // [w] S[d+1]
@@ -305,44 +452,47 @@ __global__ __launch_bounds__(256) void wta2_kernel(const SumArgs a, int m, uint1
     const int W = w + 2 * m;
     uint16_t *out = raw + ((size_t)pair * (h + 2 * m) + (y + m)) * (size_t)W + m;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane / LPP, g = lane % LPP;
+    const int r = lane >> 4, q = lane & 15;
     for (int x = threadIdx.x; x < w; x += blockDim.x)
         rkey[x] = 0xFFFFFFFFu;
     __syncthreads();
-    u32 *mytile = tile + (wave * PPW + j) * (Dp / 2);
-    for (int x0 = wave * PPW; x0 < w; x0 += 4 * PPW) {
-        const int x = x0 + j;
+    u32 *mytile = tile + (wave * 4 + r) * (Dp / 2);
+    const uint16_t *t16 = reinterpret_cast<const uint16_t *>(mytile);
+    for (int x0 = wave * 4; x0 < w; x0 += 16) {
+        const int x = x0 + r;
         const bool active = x < w;
         const int xc = active ? x : w - 1;
-        u32 S[8];
-        pixel_sums<R>(a, pair, y, xc, g, S);
+        u32 S[RP];
+        pixel_sums<RP>(a, pair, y, xc, q, S);
         u32 best = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int d = 16 * g + i;
-            const u32 v = (i & 1) ? (S[i >> 1] >> 16) : (S[i >> 1] & 0xFFFFu);
-            if (active && d < D) {
-                const u32 key = (v << 16) | (u32)d;
-                best = min(best, key);
-                if (d <= x)
-                    atomicMin(&rkey[x - d], key);
+        for (int j = 0; j < RP; j++) {
+            const int dl = RP * q + j, dh = HALF + dl;
+            const u32 kl = (S[j] << 16) | (u32)dl, kh = (S[j] & 0xFFFF0000u) | (u32)dh;
+            if (active && dl < D) {
+                best = min(best, kl);
+                if (dl <= x)
+                    atomicMin(&rkey[x - dl], kl);
+            }
+            if (active && dh < D) {
+                best = min(best, kh);
+                if (dh <= x)
+                    atomicMin(&rkey[x - dh], kh);
             }
         }
-        *reinterpret_cast<uint4 *>(mytile + 8 * g) = make_uint4(S[0], S[1], S[2], S[3]);
-        *reinterpret_cast<uint4 *>(mytile + 8 * g + 4) = make_uint4(S[4], S[5], S[6], S[7]);
-#pragma unroll
-        for (int msk = 1; msk < LPP; msk <<= 1)
-            best = min(best, (u32)__shfl_xor((int)best, msk));
+        __builtin_memcpy(mytile + RP * q, S, 4 * RP);
+        best = row_min_u32(best);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active && g == 0) {
+        if (active && q == 0) {
             lkey[x] = best;
             const int d = (int)(best & 0xFFFFu);
             if (d >= 1 && d < D - 1) {
-                const uint16_t *t16 = reinterpret_cast<const uint16_t *>(mytile);
-                s3a[x] = (u32)t16[d - 1] | ((u32)t16[d] << 16);
-                s3b[x] = (u32)t16[d + 1];
+                // element d of the tile: uint16 index 2 * (d mod HALF) + (d >= HALF)
+                auto at = [&](int dd) { return (u32)t16[2 * (dd >= HALF ? dd - HALF : dd) + (dd >= HALF ? 1 : 0)]; };
+                s3a[x] = at(d - 1) | (at(d) << 16);
+                s3b[x] = at(d + 1);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -370,23 +520,25 @@ __global__ __launch_bounds__(256) void wta2_kernel(const SumArgs a, int m, uint1
 }
 
 // S tap: the rebuilt summed path costs of one pair, dense [h][w][D] uint16.
-template <int R>
+template <int RP>
 __global__ __launch_bounds__(256) void sums_tap_kernel(const SumArgs a, int pair, uint16_t *__restrict__ out)
 {
-    constexpr int LPP = 8 * R;
+    constexpr int HALF = 16 * RP;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t pixi = t / LPP;
-    const int g = (int)(t % LPP);
+    const size_t pixi = t / 16;
+    const int q = (int)(t % 16);
     if (pixi >= (size_t)a.w * a.h)
         return;
     const int y = (int)(pixi / a.w), x = (int)(pixi % a.w);
-    u32 S[8];
-    pixel_sums<R>(a, pair, y, x, g, S);
+    u32 S[RP];
+    pixel_sums<RP>(a, pair, y, x, q, S);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int d = 16 * g + i;
-        if (d < a.D)
-            out[pixi * a.D + d] = (uint16_t)((i & 1) ? (S[i >> 1] >> 16) : (S[i >> 1] & 0xFFFFu));
+    for (int j = 0; j < RP; j++) {
+        const int dl = RP * q + j, dh = HALF + dl;
+        if (dl < a.D)
+            out[pixi * a.D + dl] = (uint16_t)(S[j] & 0xFFFFu);
+        if (dh < a.D)
+            out[pixi * a.D + dh] = (uint16_t)(S[j] >> 16);
     }
 }
 
