@@ -316,6 +316,9 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
                 prior[j] = pk_max(prior[j], padfloor[j]);
         }
         if (!SLOW) {
+#ifdef SGMX_EXP_NOSTORE
+            if (e[0] == 0x12345678u)
+#endif
             buf_store_e<RP>(rsE, voE, soE, e);
         } else if (t < len) {
             buf_store_e<RP>(rsE, voE, soE, e);
