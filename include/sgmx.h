@@ -109,6 +109,14 @@ SGMX_API int sgmx_compute_cost_f32(sgmx_ctx *ctx, const float *cost, int W, int 
 SGMX_API int sgmx_compute_cost_f32_dev(sgmx_ctx *ctx, int n, const float *d_cost, int W, int H, int D,
                                        uint16_t *d_disp, void *stream);
 
+/* The whole of cv::Mat recon::SGM::Compute(left_desc_path, right_desc_path) (sgm.h:65,
+ * sgm.cc:14-174) after the two descriptor files are in memory (LoadRepresentationFromFile,
+ * sgm.h:378-410): desc_left/right are the [H][W][K] float tensors; the L2 data cost of
+ * sgm.cc:76-84 is built on the GPU (float32, differences summed in index order), then the float
+ * path above runs on it.  disp: H x W uint16, dense. */
+SGMX_API int sgmx_compute_desc_f32(sgmx_ctx *ctx, const float *desc_left, const float *desc_right, int W, int H, int K,
+                                   uint16_t *disp);
+
 /* ---- stage taps (host pointers; for parity tests and debugging) ---- */
 
 /* StereoCosts::census_transform (stereo_costs.cc:36-61): out is (H-2m) x (W-2m) uint32. */

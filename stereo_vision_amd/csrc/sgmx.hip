@@ -637,6 +637,45 @@ int sgmx_compute_cost_f32(sgmx_ctx *c, const float *cost, int W, int H, int D, u
     return SGMX_OK;
 }
 
+int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc_right, int W, int H, int K,
+                          uint16_t *disp)
+{
+    if (!c || !desc_left || !desc_right || !disp || K < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or K < 1");
+    int rc = check_size(c, W, H, false);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    rc = ensure_scratch(c, 2, W, H);
+    if (rc)
+        return rc;
+    const size_t npix = (size_t)W * H, nb = npix * K * sizeof(float);
+    float *d_f = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_f, 2 * nb));
+    hipStream_t st = c->own_stream;
+    hipError_t e = hipMemcpyAsync(d_f, desc_left, nb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_f + npix * K, desc_right, nb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const size_t tot = npix * c->Dp;
+        hipLaunchKernelGGL(descriptor_cost_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_f,
+                           d_f + npix * K, W, K, c->prm.disp_range, c->Dp, (float *)c->d_C, tot);
+        rc = run_aggregation(c, 1, true, st);
+        if (!rc)
+            rc = run_wta_median(c, 1, true, c->d_out, st);
+        c->last_n = 1;
+        if (!rc)
+            e = hipMemcpyAsync(disp, c->d_out, npix * 2, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_f);
+    if (rc)
+        return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("descriptor path copy/sync: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
 int sgmx_census_u32(sgmx_ctx *c, const uint8_t *img, int W, int H, int stride, uint32_t *out)
 {
     if (!c || !img || !out || stride < W)

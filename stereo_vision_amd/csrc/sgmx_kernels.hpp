@@ -723,6 +723,36 @@ __global__ __launch_bounds__(256) void data_cost_wta_kernel(const uint8_t *__res
     out[(size_t)(y + m) * (w + 2 * m) + (x + m)] = (uint8_t)d;
 }
 
+// Descriptor data cost (sgm.cc:76-84, initialisation sgm.cc:55): C[y][x][d] = ||fL[y][x] - fR[y][x-d]||_2
+// for x >= d, FLT_MAX otherwise; pad disparities d >= D get 0.  One thread per voxel, the K
+// differences summed left to right in float32 (Eigen's own reduction order is build dependent).
+__global__ __launch_bounds__(256) void descriptor_cost_kernel(const float *__restrict__ fl, const float *__restrict__ fr,
+                                                              int w, int K, int D, int Dp, float *__restrict__ C,
+                                                              size_t total)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total)
+        return;
+    const size_t pix = t / Dp;
+    const int d = (int)(t - pix * Dp);
+    const int x = (int)(pix % (size_t)w);
+    float v;
+    if (d >= D) {
+        v = 0.f;
+    } else if (d > x) {
+        v = 3.402823466e+38f;
+    } else {
+        const float *a = fl + pix * K, *b = fr + (pix - d) * K;
+        float s = 0.f;
+        for (int k = 0; k < K; k++) {
+            const float df = a[k] - b[k];
+            s += df * df;
+        }
+        v = __builtin_sqrtf(s);
+    }
+    C[t] = v;
+}
+
 __global__ __launch_bounds__(256) void hamming_matrix_kernel(uint16_t *__restrict__ dis, const uint8_t *__restrict__ a,
                                                              const uint8_t *__restrict__ b, int na, int nb, int ncodes)
 {

@@ -1,0 +1,205 @@
+"""Callers of the SGM engine: counterparts of the reference's CLI mains and batch scripts.
+
+    reference                                              here
+    reconstruction/main/sgm_single/main.cc:11-79            sgm_single(left, right, out_folder, P1, P2)
+    reconstruction/main/sgm_cnn/main.cc:11-74               sgm_cnn(left_desc, right_desc, out_dir, prefix, P1, P2)
+    scripts/run_sgm_batch_census.py:14-34                   list_census_pairs, make_output_dirs, run_batch_census
+    scripts/run_sgm_batch_cnn.py:22-42                      list_cnn_pairs, run_batch_cnn
+
+Same file-selection rules, argv meaning and output files.  The reference runs one process per
+pair, strictly sequentially; here a rank takes a contiguous slice of the pair list (one process
+per GPU, no data-path collective -- stereo pairs are independent) and feeds the engine in batches.
+Image decoding / PNG encoding and the 8-bit preview arithmetic are host-side caller code in the
+reference too (OpenCV); all SGM arithmetic happens in libsgmx.so on the GPU.
+"""
+import os
+from os.path import isfile, join
+
+import numpy as np
+
+from .sgm import SGM, SGMParams, StereoSGM, StereoSGMParams
+
+
+# ---------------------------------------------------------------- sharding / statistics
+def shard_range(n_items, rank, world):
+    """Contiguous slice [lo, hi) of n_items for `rank` of `world`:
+    ceil(n / world) items per rank, the last ranks may get fewer or none."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank/world")
+    per = -(-n_items // world)
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+FNV_OFFSET = 1469598103934665603
+FNV_PRIME = 1099511628211
+
+
+def fnv_u16(img):
+    """Checksum of a disparity map, one update per uint16 pixel."""
+    h = FNV_OFFSET
+    for v in np.asarray(img, np.uint16).reshape(-1).tolist():
+        h = ((h ^ v) * FNV_PRIME) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def gather_stats(frames, seconds, checksum_xor=0):
+    """Whole-job statistics over all ranks: total frames, the slowest rank's time and the XOR of
+    the per-rank checksums.  Uses torch.distributed when a process group exists (RCCL on GPUs,
+    gloo in the CPU tests); a single process returns its own numbers."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dict(frames=int(frames), seconds=float(seconds), checksum_xor=int(checksum_xor), world=1)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(frames)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    s = torch.tensor([float(seconds)], dtype=torch.float64, device=dev)
+    dist.all_reduce(s, op=dist.ReduceOp.MAX)
+    # 64-bit checksums travel as two 32-bit halves (int64 tensors cannot hold an unsigned 64-bit value)
+    c = torch.tensor([checksum_xor >> 32, checksum_xor & 0xFFFFFFFF], dtype=torch.int64, device=dev)
+    parts = [torch.zeros_like(c) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, c)
+    x = 0
+    for p in parts:
+        hi, lo = (int(v) for v in p.cpu().tolist())
+        x ^= (hi << 32) | lo
+    return dict(frames=int(t.item()), seconds=float(s.item()), checksum_xor=x, world=dist.get_world_size())
+
+
+# ---------------------------------------------------------------- file selection
+def list_census_pairs(left_dir, right_dir, token="_10.png"):
+    """scripts/run_sgm_batch_census.py:25-31: every file of left_dir whose name contains
+    "_10.png"; the right image has the same name in right_dir.  Sorted for determinism."""
+    names = sorted(f for f in os.listdir(left_dir) if isfile(join(left_dir, f)) and token in f)
+    return [(join(left_dir, f), join(right_dir, f)) for f in names]
+
+
+def list_cnn_pairs(data_folder):
+    """scripts/run_sgm_batch_cnn.py:33-41: every file whose name contains "left";
+    prefix = name[:9]; right = prefix + "_right.bin".  Returns (left, right, prefix)."""
+    names = sorted(f for f in os.listdir(data_folder) if isfile(join(data_folder, f)) and "left" in f)
+    return [(join(data_folder, f), join(data_folder, f[:9] + "_right.bin"), f[:9]) for f in names]
+
+
+def make_output_dirs(out_folder):
+    """scripts/run_sgm_batch_census.py:14-23 / run_sgm_batch_cnn.py:25-31."""
+    existed = os.path.exists(out_folder)
+    for sub in ("", "disparities", "norm_hist", "interpolation"):
+        os.makedirs(join(out_folder, sub), exist_ok=True)
+    if existed:
+        print("WARNING: path exists - ", out_folder)
+    return not existed
+
+
+# ---------------------------------------------------------------- image I/O and previews
+def read_gray(path):
+    from PIL import Image
+    return np.ascontiguousarray(np.array(Image.open(path).convert("L"), dtype=np.uint8))
+
+
+def write_png16(path, disp):
+    """16-bit PNG, value = 256 * disparity, 0 = invalid (what cv::imwrite does with a CV_16U Mat;
+    the KITTI devkit format, reconstruction/evaluation/io_disp.h:220-238)."""
+    from PIL import Image
+    Image.fromarray(np.ascontiguousarray(disp, np.uint16)).save(path)
+
+
+def read_png16(path):
+    from PIL import Image
+    return np.array(Image.open(path)).astype(np.uint16)
+
+
+def to_u8_div256(disp):
+    """img_disp.convertTo(img8, CV_8U, 1.0/256.0) (sgm_single/main.cc:45): round half to even, saturate."""
+    return np.clip(np.rint(disp.astype(np.float64) / 256.0), 0, 255).astype(np.uint8)
+
+
+def normalize_minmax_u8(img8):
+    """cv::normalize(src, dst, 0, 255, cv::NORM_MINMAX) on CV_8U (sgm_single/main.cc:56)."""
+    lo, hi = int(img8.min()), int(img8.max())
+    if hi == lo:
+        return np.zeros_like(img8)
+    scale = 255.0 / (hi - lo)
+    return np.clip(np.rint((img8.astype(np.float64) - lo) * scale), 0, 255).astype(np.uint8)
+
+
+def stem(path):
+    """sgm_single/main.cc:47-51: strip the directory and the last extension."""
+    name = path[path.rfind("/") + 1:]
+    dot = name.rfind(".")
+    return name[:dot] if dot != -1 else name
+
+
+def write_outputs(out_folder, prefix, disp):
+    from PIL import Image
+    write_png16(join(out_folder, "disparities", prefix + ".png"), disp)
+    Image.fromarray(normalize_minmax_u8(to_u8_div256(disp))).save(join(out_folder, "norm_hist", prefix + ".png"))
+
+
+# ---------------------------------------------------------------- single-pair mains
+def sgm_single(left_img_fname, right_img_fname, out_folder, P1, P2, disp_range=256, window_sz=3, engine=None,
+               device=0):
+    """sgm_single left right out_folder P1 P2 (sgm_single/main.cc:11-79).  The reference hard-codes
+    disp_range = 256 and window_sz = 3 (:29-32); they are options here."""
+    eng = engine or StereoSGM(StereoSGMParams(disp_range=disp_range, window_sz=window_sz, penalty1=P1, penalty2=P2,
+                                              device=device))
+    disp = eng.compute(read_gray(left_img_fname), read_gray(right_img_fname))
+    write_outputs(out_folder, stem(left_img_fname), disp)
+    return disp
+
+
+def sgm_cnn(left_desc_path, right_desc_path, out_dir, prefix, P1, P2, disp_range=255, engine=None, device=0):
+    """sgm_cnn left right out_folder prefix P1 P2 (sgm_cnn/main.cc:11-74; disp_range = 255 at :24)."""
+    eng = engine or SGM(SGMParams(disp_range=disp_range, penalty1=P1, penalty2=P2, device=device))
+    disp = eng.Compute(left_desc_path, right_desc_path)
+    write_outputs(out_dir, prefix, disp)
+    return disp
+
+
+# ---------------------------------------------------------------- batch drivers
+def run_batch_census(left_dir, right_dir, out_folder, P1=3, P2=60, disp_range=256, window_sz=3, rank=0, world=1,
+                     device=0, batch=8, write=True):
+    """scripts/run_sgm_batch_census.py over this rank's slice of the pair list.  Pairs of equal
+    size are sent to the engine `batch` at a time.  Returns (frames, xor of the output checksums)."""
+    pairs = list_census_pairs(left_dir, right_dir)
+    lo, hi = shard_range(len(pairs), rank, world)
+    if rank == 0 and write:
+        make_output_dirs(out_folder)
+    eng = StereoSGM(StereoSGMParams(disp_range=disp_range, window_sz=window_sz, penalty1=P1, penalty2=P2,
+                                    device=device, max_batch=batch))
+    frames, cks = 0, 0
+    i = lo
+    while i < hi:
+        group = [(read_gray(l), read_gray(r), l) for l, r in pairs[i:min(hi, i + batch)]]
+        n = 1
+        while n < len(group) and group[n][0].shape == group[0][0].shape:
+            n += 1
+        group = group[:n]
+        disp = eng.compute_batch(np.stack([g[0] for g in group]), np.stack([g[1] for g in group]))
+        for g, d in zip(group, disp):
+            print(os.path.basename(g[2]))
+            if write:
+                write_outputs(out_folder, stem(g[2]), d)
+            cks ^= fnv_u16(d)
+        frames += n
+        i += n
+    return frames, cks
+
+
+def run_batch_cnn(data_folder, out_folder, P1=3, P2=60, disp_range=255, rank=0, world=1, device=0, write=True):
+    """scripts/run_sgm_batch_cnn.py over this rank's slice of the descriptor list."""
+    items = list_cnn_pairs(data_folder)
+    lo, hi = shard_range(len(items), rank, world)
+    if rank == 0 and write:
+        make_output_dirs(out_folder)
+    eng = SGM(SGMParams(disp_range=disp_range, penalty1=P1, penalty2=P2, device=device))
+    frames, cks = 0, 0
+    for left, right, prefix in items[lo:hi]:
+        print(os.path.basename(left))
+        disp = eng.Compute(left, right)
+        if write:
+            write_outputs(out_folder, prefix, disp)
+        cks ^= fnv_u16(disp)
+        frames += 1
+    return frames, cks

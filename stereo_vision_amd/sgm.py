@@ -164,6 +164,15 @@ class StereoSGM(Engine):
         return out
 
 
+def save_representation(path, tensor):
+    """Writer for the descriptor format of sgm.h:378-410 (the reference only reads it)."""
+    t = np.ascontiguousarray(tensor, np.float32)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", 3))
+        f.write(struct.pack("<3Q", *t.shape))
+        t.tofile(f)
+
+
 def load_representation(path):
     """SGM::LoadRepresentationFromFile (sgm.h:378-410): int32 dims (= 3), uint64 size[3]
     = {H, W, K}, float32[H][W][K]."""
@@ -188,6 +197,22 @@ class SGM(Engine):
         disp = np.empty((H, W), np.uint16)
         self.check(self.lib.sgmx_compute_cost_f32(self.h, _ptr(cost), W, H, D, _ptr(disp)))
         return disp
+
+    def compute_desc(self, desc_left, desc_right):
+        """(H, W, K) float32 descriptor tensors -> (H, W) uint16: L2 data cost (sgm.cc:76-84) on the
+        GPU, then the float path."""
+        fl = np.ascontiguousarray(desc_left, np.float32)
+        fr = np.ascontiguousarray(desc_right, np.float32)
+        if fl.shape != fr.shape or fl.ndim != 3:
+            raise ValueError("want two (H, W, K) float32 tensors of equal shape")
+        H, W, K = fl.shape
+        disp = np.empty((H, W), np.uint16)
+        self.check(self.lib.sgmx_compute_desc_f32(self.h, _ptr(fl), _ptr(fr), W, H, K, _ptr(disp)))
+        return disp
+
+    def Compute(self, left_desc_path, right_desc_path):
+        """cv::Mat SGM::Compute(left_desc_path, right_desc_path) (sgm.h:65, sgm.cc:14-174)."""
+        return self.compute_desc(load_representation(left_desc_path), load_representation(right_desc_path))
 
     def compute_cost_device(self, d_cost, d_disp, n, W, H, stream=0):
         self.check(self.lib.sgmx_compute_cost_f32_dev(self.h, n, d_cost, W, H, self.params.disp_range, d_disp, stream))
