@@ -341,18 +341,31 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
         const SumArgs sa = sum_args(c);
         const size_t lds = wta3_lds_bytes(c);
         const dim3 grid(c->h, n);
-        const void *fn = c->RP == 1 ? (const void *)wta3_kernel<1> : c->RP == 2 ? (const void *)wta3_kernel<2>
-                       : c->RP == 4 ? (const void *)wta3_kernel<4> : (const void *)wta3_kernel<8>;
-        if (lds > 64 * 1024) // beyond the default dynamic-LDS limit
-            HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const bool wpad = c->prm.disp_range != c->DpF;
+        const int P2 = c->prm.penalty2;
+#define SGMX_WTA(RPV)                                                                                                  \
+    do {                                                                                                               \
+        if (wpad) {                                                                                                    \
+            if (lds > 64 * 1024)                                                                                       \
+                HIPCHK(c, hipFuncSetAttribute((const void *)wta3_kernel<RPV, true>,                                    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            hipLaunchKernelGGL((wta3_kernel<RPV, true>), grid, dim3(256), lds, st, sa, P2, c->m, c->d_raw);             \
+        } else {                                                                                                       \
+            if (lds > 64 * 1024)                                                                                       \
+                HIPCHK(c, hipFuncSetAttribute((const void *)wta3_kernel<RPV, false>,                                   \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            hipLaunchKernelGGL((wta3_kernel<RPV, false>), grid, dim3(256), lds, st, sa, P2, c->m, c->d_raw);            \
+        }                                                                                                              \
+    } while (0)
         if (c->RP == 1)
-            hipLaunchKernelGGL(wta3_kernel<1>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+            SGMX_WTA(1);
         else if (c->RP == 2)
-            hipLaunchKernelGGL(wta3_kernel<2>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+            SGMX_WTA(2);
         else if (c->RP == 4)
-            hipLaunchKernelGGL(wta3_kernel<4>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+            SGMX_WTA(4);
         else
-            hipLaunchKernelGGL(wta3_kernel<8>, grid, dim3(256), lds, st, sa, c->m, c->d_raw);
+            SGMX_WTA(8);
+#undef SGMX_WTA
         HIPCHK(c, hipGetLastError());
     }
     {

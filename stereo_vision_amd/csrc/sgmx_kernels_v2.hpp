@@ -394,35 +394,66 @@ template <> __device__ __forceinline__ void load_e_pairs<8>(const uint8_t *p, u3
     }
 }
 
+// Raw inputs of one pixel's S for one lane: loaded one iteration ahead of their use.
+template <int RP> struct PixelRaw {
+    u32 clv, wl[RP], wh[RP];
+    u32 ev[8][(RP + 1) / 2]; // RP = 1: the two bytes sit in the low half of ev[k][0]
+};
+
 template <int RP>
-__device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, int x, int q, u32 (&S)[RP])
+__device__ __forceinline__ void load_pixel(const SumArgs &a, int pair, int y, int x, int q, PixelRaw<RP> &r)
 {
     constexpr int Dp = 32 * RP, HALF = 16 * RP;
     const size_t pix = ((size_t)pair * a.h + y) * a.w + x;
-    const u32 clv = a.cl[pix];
-    u32 wl[RP], wh[RP];
+    r.clv = a.cl[pix];
     const u32 *win = a.cr + ((size_t)pair * a.h + y) * a.wp + (Dp + x - RP * q - (RP - 1));
-    __builtin_memcpy(wl, win, 4 * RP);
-    __builtin_memcpy(wh, win - HALF, 4 * RP);
+    __builtin_memcpy(r.wl, win, 4 * RP);
+    __builtin_memcpy(r.wh, win - HALF, 4 * RP);
     const uint8_t *ep = a.E + pix * Dp + 2 * RP * q;
-    u32 ev[8][RP];
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        if (k < a.N)
-            load_e_pairs<RP>(ep + (size_t)k * a.estride, ev[k]);
+        if (k < a.N) {
+            if (RP == 1)
+                r.ev[k][0] = *reinterpret_cast<const unsigned short *>(ep + (size_t)k * a.estride);
+            else
+                __builtin_memcpy(r.ev[k], ep + (size_t)k * a.estride, 2 * RP);
+        }
+}
+
+// S = N C + sum_k E_k.  The E bytes of G volumes are added as packed bytes first (no carry while
+// G * P2 <= 255), then widened to the packed uint16 pairs.
+template <int RP, int G, bool MASK>
+__device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &r, int tl, u32 (&S)[RP])
+{
+    constexpr int NW = (RP + 1) / 2;
     u32 c[RP];
-    cost_from_census<RP, true>(wl, wh, clv, x - RP * q, c);
+    cost_from_census<RP, MASK>(r.wl, r.wh, r.clv, tl, c);
     const int sh = a.N == 8 ? 3 : 2;
 #pragma unroll
     for (int j = 0; j < RP; j++)
         S[j] = c[j] << sh; // N * C
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (k < a.N) {
+    for (int k0 = 0; k0 < 8; k0 += G)
+        if (k0 < a.N) {
+            u32 acc[NW];
+#pragma unroll
+            for (int m = 0; m < NW; m++)
+                acc[m] = r.ev[k0][m];
+#pragma unroll
+            for (int k = k0 + 1; k < k0 + G; k++)
+#pragma unroll
+                for (int m = 0; m < NW; m++)
+                    acc[m] += r.ev[k][m];
 #pragma unroll
             for (int j = 0; j < RP; j++)
-                S[j] = pk_add(S[j], ev[k][j]);
+                S[j] = pk_add(S[j], __builtin_amdgcn_perm(0u, acc[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u));
         }
+}
+
+template <int RP>
+__device__ __forceinline__ void add_border(const SumArgs &a, int pair, int y, int x, int q, u32 (&S)[RP])
+{
+    constexpr int Dp = 32 * RP;
     if (y == 0 || y == a.h - 1 || x == 0 || x == a.w - 1) {
         u32 sb[RP];
         __builtin_memcpy(sb, reinterpret_cast<const u32 *>(a.SB) +
@@ -434,14 +465,24 @@ __device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, in
     }
 }
 
+template <int RP>
+__device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, int x, int q, u32 (&S)[RP])
+{
+    PixelRaw<RP> r;
+    load_pixel<RP>(a, pair, y, x, q, r);
+    sum_pixel<RP, 1, true>(a, r, x - RP * q, S);
+    add_border<RP>(a, pair, y, x, q, S);
+}
+
 // ---------------------------------------------------------------------------
 // K4+K5' WTA, right-view argmin, LR check, subpixel (stereo_sgm.h:209-241, 275-317) on the
-// rebuilt S.  One workgroup per image row; a wave handles 4 pixels at a time (one per DPP row).
-// Right view: LDS atomicMin of (cost << 16 | d) keys into slot x-d, i.e. the reference's diagonal
-// scan S[y][xr+i][i] regrouped by xr; the smaller d wins ties like its strict '<' scan.
+// rebuilt S.  One workgroup per image row; a wave handles 4 pixels at a time (one per DPP row),
+// with the next 4 pixels' loads in flight.  Right view: LDS atomicMin of (cost << 16 | d) keys
+// into slot x-d, i.e. the reference's diagonal scan S[y][xr+i][i] regrouped by xr; the smaller d
+// wins ties like its strict '<' scan.
 // ---------------------------------------------------------------------------
-template <int RP>
-__global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint16_t *__restrict__ raw)
+template <int RP, bool HAS_PAD>
+__global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int m, uint16_t *__restrict__ raw)
 {
     constexpr int Dp = 32 * RP, HALF = 16 * RP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -454,33 +495,76 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint1
     const int y = blockIdx.x, pair = blockIdx.y;
     const int W = w + 2 * m;
     uint16_t *out = raw + ((size_t)pair * (h + 2 * m) + (y + m)) * (size_t)W + m;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane >> 4, q = lane & 15;
     for (int x = threadIdx.x; x < w; x += blockDim.x)
         rkey[x] = 0xFFFFFFFFu;
     __syncthreads();
     u32 *mytile = tile + (wave * 4 + r) * (Dp / 2);
     const uint16_t *t16 = reinterpret_cast<const uint16_t *>(mytile);
+    const int G = P2 <= 31 ? 8 : (P2 <= 63 ? 4 : (P2 <= 127 ? 2 : 1)); // volumes whose bytes add without carry
+    const bool border_row = y == 0 || y == h - 1;
+
+    auto clampx = [&](int x0) { const int x = x0 + r; return x < w ? x : w - 1; };
+    PixelRaw<RP> cur;
+    if (wave * 4 < w)
+        load_pixel<RP>(a, pair, y, clampx(wave * 4), q, cur);
     for (int x0 = wave * 4; x0 < w; x0 += 16) {
         const int x = x0 + r;
-        const bool active = x < w;
-        const int xc = active ? x : w - 1;
+        PixelRaw<RP> nxt;
+        const bool more = x0 + 16 < w;
+        if (more)
+            load_pixel<RP>(a, pair, y, clampx(x0 + 16), q, nxt);
+        const bool full = x0 >= D - 1 && x0 + 3 < w; // every lane: pixel inside the row, every d <= x
+        const int xc = x < w ? x : w - 1;
+        const int xb = xc - RP * q;                  // x - d_lo of register 0
         u32 S[RP];
-        pixel_sums<RP>(a, pair, y, xc, q, S);
+        if (full) {
+            if (G == 8)
+                sum_pixel<RP, 8, false>(a, cur, xb, S);
+            else if (G == 4)
+                sum_pixel<RP, 4, false>(a, cur, xb, S);
+            else if (G == 2)
+                sum_pixel<RP, 2, false>(a, cur, xb, S);
+            else
+                sum_pixel<RP, 1, false>(a, cur, xb, S);
+        } else {
+            sum_pixel<RP, 1, true>(a, cur, xb, S);
+        }
+        if (border_row || x0 == 0 || x0 + 3 >= w - 1)
+            add_border<RP>(a, pair, y, xc, q, S);
         u32 best = 0xFFFFFFFFu;
+        u32 *rb = rkey + (xb - (RP - 1) - HALF); // slot of this lane's largest disparity; may lie below rkey when !full
+        if (full) {
 #pragma unroll
-        for (int j = 0; j < RP; j++) {
-            const int dl = RP * q + j, dh = HALF + dl;
-            const u32 kl = (S[j] << 16) | (u32)dl, kh = (S[j] & 0xFFFF0000u) | (u32)dh;
-            if (active && dl < D) {
-                best = min(best, kl);
-                if (dl <= x)
-                    atomicMin(&rkey[x - dl], kl);
+            for (int j = 0; j < RP; j++) {
+                const int dl = RP * q + j, dh = HALF + dl;
+                const u32 kl = (S[j] << 16) | (u32)dl, kh = (S[j] & 0xFFFF0000u) | (u32)dh;
+                if (!HAS_PAD || dl < D) {
+                    best = min(best, kl);
+                    atomicMin(rb + (RP - 1 - j) + HALF, kl);
+                }
+                if (!HAS_PAD || dh < D) {
+                    best = min(best, kh);
+                    atomicMin(rb + (RP - 1 - j), kh);
+                }
             }
-            if (active && dh < D) {
-                best = min(best, kh);
-                if (dh <= x)
-                    atomicMin(&rkey[x - dh], kh);
+        } else {
+            const bool active = x < w;
+#pragma unroll
+            for (int j = 0; j < RP; j++) {
+                const int dl = RP * q + j, dh = HALF + dl;
+                const u32 kl = (S[j] << 16) | (u32)dl, kh = (S[j] & 0xFFFF0000u) | (u32)dh;
+                if (active && dl < D) {
+                    best = min(best, kl);
+                    if (dl <= x)
+                        atomicMin(rb + (RP - 1 - j) + HALF, kl);
+                }
+                if (active && dh < D) {
+                    best = min(best, kh);
+                    if (dh <= x)
+                        atomicMin(rb + (RP - 1 - j), kh);
+                }
             }
         }
         __builtin_memcpy(mytile + RP * q, S, 4 * RP);
@@ -488,7 +572,7 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint1
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active && q == 0) {
+        if (x < w && q == 0) {
             lkey[x] = best;
             const int d = (int)(best & 0xFFFFu);
             if (d >= 1 && d < D - 1) {
@@ -500,6 +584,8 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint1
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier(); // the tile is overwritten by the next iteration
+        if (more)
+            cur = nxt;
     }
     __syncthreads();
     for (int x = threadIdx.x; x < w; x += blockDim.x) {
