@@ -395,8 +395,15 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
     const int W = c->W, H = c->H, w = c->w, h = c->h;
     {
         ProfScope ps(c, SGMX_K_CENSUS, st);
-        hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 2 * n), dim3(256), 0, st, dL, dR, n, W, H,
-                           c->prm.window_sz, c->d_cl, c->d_cr, c->wp, c->fast ? c->DpF : 0);
+        const int xoff = c->fast ? c->DpF : 0;
+        const dim3 g4((w + 1023) / 1024, h, 2 * n);
+        if (c->prm.window_sz == 5 && W >= 8)
+            hipLaunchKernelGGL(census4_kernel<5>, g4, dim3(256), 0, st, dL, dR, n, W, H, c->d_cl, c->d_cr, c->wp, xoff);
+        else if (c->prm.window_sz == 3 && W >= 8)
+            hipLaunchKernelGGL(census4_kernel<3>, g4, dim3(256), 0, st, dL, dR, n, W, H, c->d_cl, c->d_cr, c->wp, xoff);
+        else
+            hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 2 * n), dim3(256), 0, st, dL, dR, n, W, H,
+                               c->prm.window_sz, c->d_cl, c->d_cr, c->wp, xoff);
         HIPCHK(c, hipGetLastError());
     }
     if (c->fast) {

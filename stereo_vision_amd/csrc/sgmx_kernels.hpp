@@ -105,6 +105,53 @@ __global__ __launch_bounds__(256) void census_kernel(const uint8_t *__restrict__
     out[x] = code;
 }
 
+// Census for the common small windows: one thread produces 4 adjacent pixels from WSZ row
+// segments of WSZ + 3 bytes each, loaded as two (unaligned) dwords instead of byte by byte.
+// Same bit order as above.  Needs w >= 1; columns past the row end are clamped and discarded.
+template <int WSZ>
+__global__ __launch_bounds__(256) void census4_kernel(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
+                                                      int n, int W, int H, u32 *__restrict__ cens_left,
+                                                      u32 *__restrict__ cens_right, int wpr, int xoffr)
+{
+    constexpr int M = (WSZ - 1) / 2;
+    const int w = W - 2 * M, h = H - 2 * M;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    const int z = blockIdx.z;
+    if (x >= w || y >= h)
+        return;
+    const uint8_t *img = (z < n ? left + (size_t)z * W * H : right + (size_t)(z - n) * W * H);
+    u32 *out = (z < n ? cens_left + (size_t)z * w * h + (size_t)y * w
+                      : cens_right + (size_t)(z - n) * wpr * h + (size_t)y * wpr + xoffr);
+    // bytes x .. x+7 of each window row (WSZ + 3 <= 8 of them are used); the last threads of a row
+    // would reach past the image row, so their segment start is pulled back (W >= 8) and the pixels
+    // are re-indexed by `sh`
+    const int xs = x + 8 <= W ? x : W - 8;
+    const int sh = x - xs;
+    unsigned long long seg[WSZ];
+#pragma unroll
+    for (int r = 0; r < WSZ; r++)
+        __builtin_memcpy(&seg[r], img + (size_t)(y + r) * W + xs, 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (x + i >= w)
+            break;
+        const int o = (i + sh) * 8; // bit offset of the window's first column
+        const u32 c = (u32)(seg[M] >> (o + 8 * M)) & 0xFFu;
+        u32 code = 0;
+#pragma unroll
+        for (int r = 0; r < WSZ; r++)
+#pragma unroll
+            for (int k = 0; k < WSZ; k++) {
+                if (r == M && k == M)
+                    continue;
+                const u32 v = (u32)(seg[r] >> (o + 8 * k)) & 0xFFu;
+                code = (code << 1) + (v > c ? 1u : 0u);
+            }
+        out[x + i] = code;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K2 Hamming data-cost volume.  One thread per (pixel, group of 16 disparities),
 // one 16-byte store each, disparity groups fastest so a wave writes whole lines.
