@@ -141,7 +141,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8 cost / u16 path cost",
+        "dtype": "u16",
         "data": "synthetic",
         "config": {"workload": "KITTI-size %dx%d census/Hamming SGM, D=%d, %d paths, wsz=%d, P1=%d, P2=%d" %
                                (W, H, D, args.paths, args.wsz, args.p1, args.p2),
@@ -149,17 +149,30 @@ def main():
     }
 
     if rank == 0:
-        # dominant kernel = the direction sweeps; algorithmic bytes of one launch (one direction
-        # over the launch group of B pairs) = B * V * (5N-2)/N on average over the N launches
+        # Dominant kernel = the direction sweeps.  Algorithmic bytes of one launch (one direction over
+        # the launch group of B pairs) = B * V * (5N-2)/N on average over the N launches:
+        # the "materialised C + S volumes" model of SURVEY.md 8d.  The default engine path no longer moves
+        # those bytes (it recomputes C and stores one byte per voxel), so `traffic` -- HBM bytes per launch
+        # from the PMC passes in profiles/ -- is far below it and `frac` can exceed 1.
+        fast = args.p2 <= 255 and D <= 256
         agg_ms, agg_n = stats["aggregate"]
         roof = None
         if agg_n:
             per_launch_bytes = B * alg_agg / args.paths
             avg_s = agg_ms / agg_n * 1e-3
             ach = per_launch_bytes / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "aggregate_u16_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_ms": round(agg_ms / agg_n, 4), "alg_bytes_per_launch": per_launch_bytes,
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_fast_hbm_traffic.json")
+            if fast and os.path.exists(tfile):
+                t = json.load(open(tfile))
+                cfg = t.get("config", {})
+                if cfg == {"batch": B, "width": W, "height": H, "disp": D, "paths": args.paths, "wsz": args.wsz}:
+                    traffic = t["kernels"]["aggregate3_kernel"]["hbm_bytes_per_launch"]
+            roof = {"bound": "hbm", "kernel": "aggregate3_kernel" if fast else "aggregate_u16_kernel",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "avg_launch_ms": round(agg_ms / agg_n, 4),
+                    "alg_bytes_per_launch": per_launch_bytes,
+                    "hbm_GBs_from_traffic": round(traffic / avg_s / 1e9, 1) if traffic else None,
                     "whole_pipeline_alg_GBs": round(alg_total * fps / world / 1e9, 1),
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stats.items()}}
         out["roofline"] = roof
