@@ -323,7 +323,8 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
         a.P1 = c->prm.penalty1;
         a.P2 = c->prm.penalty2;
         a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
-        const dim3 grid((a.npaths + 15) / 16, n); // 4 waves x 4 paths per workgroup
+        a.npairs = n;
+        const dim3 grid(8 * ((a.npaths + 15) / 16) * ((n + 7) / 8)); // 4 waves x 4 paths per workgroup, XCD-major pairs
         uint8_t *Ek = c->d_E + (size_t)k * c->bytes_E * c->prm.max_batch;
         ProfScope ps(c, SGMX_K_AGGREGATE, st);
         if (c->RP == 1)

@@ -49,7 +49,7 @@ struct Agg2Args {
     int w, h, D, wp;   // cropped size, real disparity count, census-right row pitch
     int dx, dy;        // predecessor of (y,x) is (y-dy, x-dx)
     int P1, P2;
-    int npaths;
+    int npaths, npairs;
 };
 
 template <bool B> struct BoolC { static constexpr bool value = B; };
@@ -176,7 +176,15 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
     constexpr int Dp = 32 * RP, HALF = 16 * RP;
     const int lane = threadIdx.x & 63;
     const int q = lane & 15;
-    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // XCD-aware block -> (pair, path group) map: workgroups are dealt round-robin over the 8 XCDs, so
+    // block b lands on XCD b % 8; giving every XCD its own pairs (pair % 8 == b % 8) keeps the census
+    // images an XCD's L2 has to hold to the few pairs it is working on.  Speed only: any placement is correct.
+    const int ngroups = (a.npaths + 15) >> 4;
+    const int bi = blockIdx.x >> 3;
+    const int pair = (bi / ngroups) * 8 + (blockIdx.x & 7);
+    if (pair >= a.npairs)
+        return;
+    const int wave = (bi % ngroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave * 4 >= a.npaths)
         return;
     const int w = a.w, h = a.h, wp = a.wp;
@@ -203,11 +211,11 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
                    soE0 = sEi < 0 ? T * (unsigned)(-sEi) : 0u;
     const unsigned sR = (unsigned)sRi, sL = (unsigned)sLi, sE = (unsigned)sEi;
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(cr + (size_t)blockIdx.y * (size_t)h * wp) - soR0), 0, -1, 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(cr + (size_t)pair * (size_t)h * wp) - soR0), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(cl + (size_t)blockIdx.y * npix) - soL0), 0, -1, 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(cl + (size_t)pair * npix) - soL0), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsE =
-        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(E + (size_t)blockIdx.y * npix * Dp) - soE0, 0, -1, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(E + (size_t)pair * npix * Dp) - soE0, 0, -1, 0x00020000);
 #ifdef SGMX_EXP_SMALLSTORE
     const __amdgpu_buffer_rsrc_t rsE0 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(E), 0, -1, 0x00020000);
 #endif
@@ -216,8 +224,8 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
     const unsigned voL = (unsigned)((g.y0 * w + g.x0) * 4);
     const unsigned voE = (unsigned)((g.y0 * w + g.x0) * Dp + 2 * RP * q);
     const size_t ring = (size_t)(2 * w + 2 * h) * (Dp / 2); // uint32 units
-    u32 *BLf = reinterpret_cast<u32 *>(BL) + (size_t)blockIdx.y * ring + RP * q;
-    u32 *SBf = reinterpret_cast<u32 *>(SB) + (size_t)blockIdx.y * ring + RP * q;
+    u32 *BLf = reinterpret_cast<u32 *>(BL) + (size_t)pair * ring + RP * q;
+    u32 *SBf = reinterpret_cast<u32 *>(SB) + (size_t)pair * ring + RP * q;
 
     const u32 P1p = (u32)a.P1 * 0x10001u, P2p = (u32)a.P2 * 0x10001u;
     const int tl0 = g.x0 - RP * q; // x - RP q at step 0
