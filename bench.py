@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--paths", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -77,9 +80,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SGM engine has no CPU path")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import stereo_vision_amd as sv
 
@@ -119,7 +127,7 @@ def main():
     stats = eng.kernel_stats()
     eng.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

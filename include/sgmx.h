@@ -57,7 +57,7 @@ typedef struct sgmx_params {
     int num_paths;   /* 8 (default; order of stereo_sgm.cc:120-122) or 4 (its axis-aligned subset) */
     int device;      /* HIP device ordinal (default 0)                                           */
     int max_batch;   /* stereo pairs processed per launch group (default 1); sizes the scratch   */
-    int flags;       /* 0, or SGMX_FLAG_MATERIALIZE                                               */
+    int flags;       /* 0, or SGMX_FLAG_MATERIALIZE / SGMX_FLAG_NO_SMALL_GROUPS                   */
 } sgmx_params;
 
 /* flags: keep the data-cost volume C and the summed-cost volume S in HBM as the reference does
@@ -65,6 +65,10 @@ typedef struct sgmx_params {
  * census path recomputes C from the census images and stores one byte per voxel and direction
  * instead; the results are identical.  penalty2 > 255 always uses the materialised form. */
 #define SGMX_FLAG_MATERIALIZE 1
+/* flags: by default launch groups of at most 3 pairs (e.g. every single-pair call) run on the
+ * materialised kernels even when the volume-free formulation is eligible, because they are
+ * latency-bound and those kernels have the shorter step; this flag disables that switch. */
+#define SGMX_FLAG_NO_SMALL_GROUPS 2
 
 typedef struct sgmx_ctx sgmx_ctx;
 

@@ -40,6 +40,11 @@ struct sgmx_ctx {
     bool fast = false;         // census path without C / S volumes (sgmx_kernels_v2.hpp): P2 <= 255, D <= 256
     int RP = 4, DpF = 128;     // fast path: packed pairs per lane, padded disparity count 32 * RP
     int wp = 0;                // row pitch of the padded right census image (fast path)
+    int small_n = 0;           // fast contexts: launch groups of <= small_n pairs take the materialised kernels
+    bool last_fast = false;    // formulation the last census launch group used (for the taps)
+    u32 *d_cr_dense = nullptr; // dense right census for the materialised kernels (== d_cr in non-fast contexts)
+    void *d_BLm = nullptr;     // border ring of the materialised kernels (== d_BL in non-fast contexts)
+    size_t bytes_BLm = 0;
     int last_n = 0;            // pairs in the last launch group
 
     // device scratch (sized for max_batch pairs)
@@ -86,6 +91,12 @@ void free_scratch(sgmx_ctx *c)
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
+    if (c->d_cr_dense && c->d_cr_dense != c->d_cr)
+        (void)hipFree(c->d_cr_dense);
+    if (c->d_BLm && c->d_BLm != c->d_BL)
+        (void)hipFree(c->d_BLm);
+    c->d_cr_dense = nullptr;
+    c->d_BLm = nullptr;
     c->d_left = c->d_right = nullptr;
     c->d_cl = c->d_cr = nullptr;
     c->d_C = c->d_S = c->d_BL = nullptr;
@@ -109,7 +120,7 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
     const size_t esz_c = mode == 1 ? 1 : 4, esz_s = mode == 1 ? 2 : 4;
     c->bytes_C = npix * c->Dp * esz_c;
     c->bytes_S = npix * c->Dp * esz_s;
-    c->bytes_BL = (size_t)(2 * w + 2 * h) * c->Dp * esz_s;
+    c->bytes_BL = c->bytes_BLm = (size_t)(2 * w + 2 * h) * c->Dp * esz_s;
     if (mode == 1 && c->fast)
         c->bytes_BL = (size_t)(2 * w + 2 * h) * c->DpF * 2;
     const bool fast = mode == 1 && c->fast;
@@ -121,15 +132,25 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
         HIPCHK(c, hipMalloc((void **)&c->d_cr, (size_t)c->wp * h * 4 * B));
         HIPCHK(c, hipMemset(c->d_cr, 0, (size_t)c->wp * h * 4 * B)); // the padding columns are never written again
     }
+    HIPCHK(c, hipMalloc(&c->d_BL, c->bytes_BL * B));
     if (fast) {
         c->bytes_E = npix * c->DpF;
         HIPCHK(c, hipMalloc((void **)&c->d_E, c->bytes_E * B * c->prm.num_paths));
         HIPCHK(c, hipMalloc((void **)&c->d_SB, c->bytes_BL * B));
+        // small launch groups are latency-bound and run faster on the one-path-per-wave kernels
+        const int ns = c->small_n < B ? c->small_n : B;
+        if (ns > 0) {
+            HIPCHK(c, hipMalloc(&c->d_C, c->bytes_C * ns));
+            HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * ns));
+            HIPCHK(c, hipMalloc(&c->d_BLm, c->bytes_BLm * ns));
+            HIPCHK(c, hipMalloc((void **)&c->d_cr_dense, npix * 4 * ns));
+        }
     } else {
         HIPCHK(c, hipMalloc(&c->d_C, c->bytes_C * B));
         HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * B));
+        c->d_BLm = c->d_BL;
+        c->d_cr_dense = c->d_cr;
     }
-    HIPCHK(c, hipMalloc(&c->d_BL, c->bytes_BL * B));
     HIPCHK(c, hipMalloc((void **)&c->d_raw, nfull * 2 * B));
     HIPCHK(c, hipMalloc((void **)&c->d_out, nfull * 2 * B));
     // the zero border of the disparity image (stereo_sgm.h:280) is written once here;
@@ -207,12 +228,12 @@ template <bool F32> void launch_agg(int R, bool first, bool pad, const AggArgs &
 int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st)
 {
     const int np = c->prm.num_paths;
-    HIPCHK(c, hipMemsetAsync(c->d_BL, 0, c->bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
+    HIPCHK(c, hipMemsetAsync(c->d_BLm, 0, c->bytes_BLm * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
     for (int k = 0; k < np; k++) {
         AggArgs a;
         a.C = c->d_C;
         a.S = c->d_S;
-        a.BL = c->d_BL;
+        a.BL = c->d_BLm;
         a.w = c->w;
         a.h = c->h;
         a.D = c->prm.disp_range;
@@ -394,20 +415,26 @@ int materialize_cost(sgmx_ctx *c, int index, uint8_t *d_dst, hipStream_t st)
 int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint16_t *d_disp, hipStream_t st)
 {
     const int W = c->W, H = c->H, w = c->w, h = c->h;
+    // Both formulations give the same bits.  The fast one (4 paths per wave, no volumes) wins once the
+    // launch group fills the chip; a group of a few pairs is latency-bound and runs faster on the
+    // one-path-per-wave kernels with the C / S volumes (they then sit in the Infinity Cache anyway).
+    const bool use_fast = c->fast && n > c->small_n;
+    c->last_fast = use_fast;
     {
         ProfScope ps(c, SGMX_K_CENSUS, st);
-        const int xoff = c->fast ? c->DpF : 0;
+        u32 *cr = use_fast ? c->d_cr : c->d_cr_dense;
+        const int pitch = use_fast ? c->wp : w, xoff = use_fast ? c->DpF : 0;
         const dim3 g4((w + 1023) / 1024, h, 2 * n);
         if (c->prm.window_sz == 5 && W >= 8)
-            hipLaunchKernelGGL(census4_kernel<5>, g4, dim3(256), 0, st, dL, dR, n, W, H, c->d_cl, c->d_cr, c->wp, xoff);
+            hipLaunchKernelGGL(census4_kernel<5>, g4, dim3(256), 0, st, dL, dR, n, W, H, c->d_cl, cr, pitch, xoff);
         else if (c->prm.window_sz == 3 && W >= 8)
-            hipLaunchKernelGGL(census4_kernel<3>, g4, dim3(256), 0, st, dL, dR, n, W, H, c->d_cl, c->d_cr, c->wp, xoff);
+            hipLaunchKernelGGL(census4_kernel<3>, g4, dim3(256), 0, st, dL, dR, n, W, H, c->d_cl, cr, pitch, xoff);
         else
             hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 2 * n), dim3(256), 0, st, dL, dR, n, W, H,
-                               c->prm.window_sz, c->d_cl, c->d_cr, c->wp, xoff);
+                               c->prm.window_sz, c->d_cl, cr, pitch, xoff);
         HIPCHK(c, hipGetLastError());
     }
-    if (c->fast) {
+    if (use_fast) {
         const int rc = run_fast(c, n, d_disp, st);
         c->last_n = n;
         return rc;
@@ -416,7 +443,7 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
         ProfScope ps(c, SGMX_K_HAMMING, st);
         const size_t groups = (size_t)n * w * h * (c->Dp / 16);
         hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, c->d_cl,
-                           c->d_cr, w, 0, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
+                           c->d_cr_dense, w, 0, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
         HIPCHK(c, hipGetLastError());
     }
     int rc = run_aggregation(c, n, false, st);
@@ -468,7 +495,7 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     if (p.num_paths != 4 && p.num_paths != 8)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "num_paths must be 4 or 8");
     if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 ||
-        (p.flags & ~SGMX_FLAG_MATERIALIZE) != 0)
+        (p.flags & ~(SGMX_FLAG_MATERIALIZE | SGMX_FLAG_NO_SMALL_GROUPS)) != 0)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "negative penalty, bad max_batch or unknown flags");
     // uint16 guarantees: L_k <= 255*(k+1) + P2 on any pixel, so S <= 36*255 + 8*P2, and the
     // "no disparity" sentinel 0x7FFF must stay above every L + P1 (sgmx_kernels.hpp INF16).
@@ -487,6 +514,7 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->R = p.disp_range <= 128 ? 1 : (p.disp_range <= 256 ? 2 : 4);
     c->Dp = 128 * c->R;
     c->fast = p.penalty2 <= 255 && p.disp_range <= 256 && !(p.flags & SGMX_FLAG_MATERIALIZE);
+    c->small_n = (p.flags & SGMX_FLAG_NO_SMALL_GROUPS) ? 0 : 3; // measured crossover at KITTI size: between 3 and 4 pairs
     c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : 8));
     c->DpF = 32 * c->RP;
     if (hipSetDevice(p.device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
@@ -578,12 +606,22 @@ int sgmx_compute_census_u8(sgmx_ctx *c, const uint8_t *left, const uint8_t *righ
     if (rc)
         return rc;
     hipStream_t st = c->own_stream;
-    HIPCHK(c, hipMemcpy2DAsync(c->d_left, W, left, stride_left, W, H, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpy2DAsync(c->d_right, W, right, stride_right, W, H, hipMemcpyHostToDevice, st));
+    // dense rows go as one linear copy (a 2-D copy from pageable memory is several ms slower)
+    if (stride_left == W)
+        HIPCHK(c, hipMemcpyAsync(c->d_left, left, (size_t)W * H, hipMemcpyHostToDevice, st));
+    else
+        HIPCHK(c, hipMemcpy2DAsync(c->d_left, W, left, stride_left, W, H, hipMemcpyHostToDevice, st));
+    if (stride_right == W)
+        HIPCHK(c, hipMemcpyAsync(c->d_right, right, (size_t)W * H, hipMemcpyHostToDevice, st));
+    else
+        HIPCHK(c, hipMemcpy2DAsync(c->d_right, W, right, stride_right, W, H, hipMemcpyHostToDevice, st));
     rc = census_group(c, 1, c->d_left, c->d_right, c->d_out, st);
     if (rc)
         return rc;
-    HIPCHK(c, hipMemcpy2DAsync(disp, stride_disp, c->d_out, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, st));
+    if (stride_disp == 2 * W)
+        HIPCHK(c, hipMemcpyAsync(disp, c->d_out, (size_t)W * H * 2, hipMemcpyDeviceToHost, st));
+    else
+        HIPCHK(c, hipMemcpy2DAsync(disp, stride_disp, c->d_out, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     return SGMX_OK;
 }
@@ -805,7 +843,7 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
         return fail(c, SGMX_ERR_INVALID_ARG, "pair index outside the last launch group");
     HIPCHK(c, hipSetDevice(c->prm.device));
     HIPCHK(c, hipDeviceSynchronize());
-    const int D = c->prm.disp_range, Dp = (mode == 1 && c->fast) ? c->DpF : c->Dp;
+    const int D = c->prm.disp_range, Dp = (mode == 1 && c->last_fast) ? c->DpF : c->Dp;
     const size_t npix = (size_t)c->w * c->h, tot = npix * D;
     const size_t esz_c = mode == 1 ? 1 : 4, esz_s = mode == 1 ? 2 : 4;
     void *tmp = nullptr;
@@ -813,7 +851,7 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
     hipStream_t st = c->own_stream;
     hipError_t e = hipSuccess;
     const unsigned nb = (unsigned)((tot + 255) / 256);
-    const bool fast = mode == 1 && c->fast;
+    const bool fast = mode == 1 && c->last_fast;
     if (C && mode == 1) {
         const uint8_t *src = (const uint8_t *)c->d_C + index * c->bytes_C;
         uint8_t *vol = nullptr;
@@ -894,7 +932,7 @@ int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
     hipError_t e = hipMemsetAsync(d_o, 0, nfull, st);
     const uint8_t *src = (const uint8_t *)c->d_C + index * c->bytes_C;
     uint8_t *vol = nullptr;
-    if (c->fast) {
+    if (c->last_fast) {
         if (hipMalloc((void **)&vol, (size_t)c->w * c->h * c->DpF) != hipSuccess || materialize_cost(c, index, vol, st) != SGMX_OK) {
             (void)hipFree(d_o);
             (void)hipFree(vol);
@@ -903,7 +941,7 @@ int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
         src = vol;
     }
     hipLaunchKernelGGL(data_cost_wta_kernel, dim3((c->w + 255) / 256, c->h), dim3(256), 0, st, src, c->w, c->h,
-                       c->prm.disp_range, c->fast ? c->DpF : c->Dp, c->m, d_o);
+                       c->prm.disp_range, c->last_fast ? c->DpF : c->Dp, c->m, d_o);
     if (e == hipSuccess)
         e = hipMemcpyAsync(out, d_o, nfull, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);

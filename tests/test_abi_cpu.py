@@ -45,7 +45,7 @@ def _create(**kw):
 
 
 @pytest.mark.parametrize("kw", [dict(disp_range=1), dict(disp_range=513), dict(num_paths=5), dict(penalty1=-1),
-                                dict(window_sz=-3), dict(window_sz=4), dict(flags=7), dict(max_batch=-2)])
+                                dict(window_sz=-3), dict(window_sz=4), dict(flags=4), dict(max_batch=-2)])
 def test_create_rejects_bad_parameters(kw):
     rc, msg = _create(**kw)
     assert rc == 1 and msg  # SGMX_ERR_INVALID_ARG, with text

@@ -70,7 +70,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
+@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
 def test_pipeline_stages_bit_exact(oracle, case, flags):
     """Every stage of both census formulations: the default one (C recomputed from the census
@@ -89,7 +89,7 @@ def test_pipeline_stages_bit_exact(oracle, case, flags):
     assert np.array_equal(e.data_cost_image(H, W), oracle.data_cost_wta(want["C"], m))
 
 
-@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
+@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
 @pytest.mark.parametrize("shape", [(5, 5), (6, 40), (40, 6), (5, 300), (6, 6), (7, 5), (5, 7)])
 def test_degenerate_shapes(oracle, shape, flags):
     """Cropped images of 1 x 1, one row, one column, 2 x 2; D larger than the width."""
@@ -112,26 +112,28 @@ def test_strided_input_and_reuse(oracle):
 
 
 # ---------------------------------------------------------------- golden fixtures
-def test_tsukuba_golden(oracle, tsukuba):
+@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
+def test_tsukuba_golden(oracle, tsukuba, flags):
     from test_oracle_golden import KNOWN
     for paths in (8, 4):
-        disp = make(disp_range=16, window_sz=5, num_paths=paths).compute(*tsukuba)
+        disp = make(disp_range=16, window_sz=5, num_paths=paths, flags=flags).compute(*tsukuba)
         s, nz, fnv = KNOWN[("tsukuba", 16, 5, paths)]
         assert int(disp.sum(dtype=np.uint64)) == s and int(np.count_nonzero(disp)) == nz
         assert oracle.fnv_u16(disp) == fnv
 
 
-def test_kitti_golden_full_size(oracle, kitti):
+@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
+def test_kitti_golden_full_size(oracle, kitti, flags):
     """BASELINE config 2 at full size: KITTI 1241x376, D=128, 8 paths, wsz 5 and 3."""
     from test_oracle_golden import KNOWN
     for wsz in (5, 3):
-        disp = make(disp_range=128, window_sz=wsz).compute(*kitti)
+        disp = make(disp_range=128, window_sz=wsz, flags=flags).compute(*kitti)
         s, nz, fnv = KNOWN[("kitti", 128, wsz, 8)]
         assert int(disp.sum(dtype=np.uint64)) == s and int(np.count_nonzero(disp)) == nz
         assert oracle.fnv_u16(disp) == fnv
 
 
-@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
+@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
 def test_kitti_stages_vs_oracle(oracle, kitti, flags):
     left, right = kitti
     e = make(disp_range=128, window_sz=5, flags=flags)
@@ -148,10 +150,26 @@ def test_batch_chunks_equal_single(oracle):
     pairs = [synth_pair(100 + i, H, W, 40) for i in range(n)]
     L = np.stack([p[0] for p in pairs])
     R = np.stack([p[1] for p in pairs])
-    e = make(disp_range=64, window_sz=5, max_batch=2)  # 5 pairs -> groups of 2, 2, 1
+    e = make(disp_range=64, window_sz=5, max_batch=2, flags=sv.FLAG_NO_SMALL_GROUPS)  # 5 pairs -> groups of 2, 2, 1
     got = e.compute_batch(L, R)
     for i in range(n):
         assert np.array_equal(got[i], oracle.sgm_census(L[i], R[i], 64, 5, 3, 60, 8)), i
+
+
+def test_adaptive_groups_mix_formulations(oracle):
+    """max_batch 5 over 9 pairs: a group of 5 (volume-free kernels) then one of 4, then a
+    single-pair call on the same context (materialised kernels): all bit-exact."""
+    n, H, W = 9, 30, 140
+    pairs = [synth_pair(300 + i, H, W, 50) for i in range(n)]
+    e = make(disp_range=100, window_sz=5, max_batch=5)
+    got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.sgm_census(pairs[i][0], pairs[i][1], 100, 5, 3, 60, 8)), i
+    one = e.compute(*pairs[4])
+    assert np.array_equal(one, got[4])
+    st = e.stages(H, W)
+    want = oracle.sgm_census(pairs[4][0], pairs[4][1], 100, 5, 3, 60, 8, taps=True)
+    assert np.array_equal(st["C"], want["C"]) and np.array_equal(st["S"].astype(np.uint32), want["S"])
 
 
 def test_device_entry_point_with_torch_memory(oracle):
@@ -161,7 +179,7 @@ def test_device_entry_point_with_torch_memory(oracle):
     L = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
     R = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
     out = torch.zeros((n, H, W), dtype=torch.int16, device="cuda")
-    e = make(disp_range=128, window_sz=5, max_batch=4)
+    e = make(disp_range=128, window_sz=5, max_batch=4, flags=sv.FLAG_NO_SMALL_GROUPS)
     e.compute_device(L.data_ptr(), R.data_ptr(), out.data_ptr(), n, W, H, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(np.uint16)
