@@ -39,9 +39,7 @@ namespace sgmx {
 
 // E bytes are written once and read once, a whole launch later: non-temporal stores (aux bit 1 = nt)
 // keep them from evicting the census images out of L2 (measured: 0.84 -> 0.60 ms per sweep).
-#ifndef SGMX_EXP_STORE_AUX
-#define SGMX_EXP_STORE_AUX 2
-#endif
+constexpr int E_STORE_AUX = 2; // cache policy bits of a buffer store: 2 = nt
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -97,18 +95,18 @@ template <> __device__ __forceinline__ void buf_load_win<8>(__amdgpu_buffer_rsrc
 template <int RP> __device__ __forceinline__ void buf_store_e(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[RP]);
 template <> __device__ __forceinline__ void buf_store_e<1>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[1])
 {
-    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)__builtin_amdgcn_perm(0u, e[0], 0x0c0c0200u), rs, voff, soff, SGMX_EXP_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)__builtin_amdgcn_perm(0u, e[0], 0x0c0c0200u), rs, voff, soff, E_STORE_AUX);
 }
 template <> __device__ __forceinline__ void buf_store_e<2>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[2])
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(e[1], e[0], 0x06040200u), rs, voff, soff, SGMX_EXP_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(e[1], e[0], 0x06040200u), rs, voff, soff, E_STORE_AUX);
 }
 template <> __device__ __forceinline__ void buf_store_e<4>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[4])
 {
     u32x2 v;
     v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u);
     v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, soff, SGMX_EXP_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, soff, E_STORE_AUX);
 }
 template <> __device__ __forceinline__ void buf_store_e<8>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[8])
 {
@@ -117,7 +115,7 @@ template <> __device__ __forceinline__ void buf_store_e<8>(__amdgpu_buffer_rsrc_
     v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
     v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u);
     v.w = __builtin_amdgcn_perm(e[7], e[6], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, SGMX_EXP_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, E_STORE_AUX);
 }
 
 // Hamming costs of a lane: wl[i] = censR[x - RP q - (RP-1) + i] (register j = RP-1-i, low half),
@@ -216,9 +214,6 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
         const_cast<char *>(reinterpret_cast<const char *>(cl + (size_t)pair * npix) - soL0), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsE =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(E + (size_t)pair * npix * Dp) - soE0, 0, -1, 0x00020000);
-#ifdef SGMX_EXP_SMALLSTORE
-    const __amdgpu_buffer_rsrc_t rsE0 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(E), 0, -1, 0x00020000);
-#endif
     // lane parts: start pixel of the lane's path + its window / line slice
     const unsigned voR = (unsigned)((g.y0 * wp + Dp + g.x0 - RP * q - (RP - 1) - HALF) * 4); // high-half window; low = + HALF*4
     const unsigned voL = (unsigned)((g.y0 * w + g.x0) * 4);
@@ -297,14 +292,8 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
         }
         const u32 clv = qcl[i];
         if (!SLOW || t + PF < len) { // census words PF steps ahead (fast blocks: in range for every row)
-#ifdef SGMX_EXP_NOWIN
-            if (SLOW || clv == 0x12345678u) {
-#endif
             buf_load_win<RP>(rsR, voR + HALF * 4, soRp, qwl[i]);
             buf_load_win<RP>(rsR, voR, soRp, qwh[i]);
-#ifdef SGMX_EXP_NOWIN
-            }
-#endif
             qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
         }
         soRp += sR;
@@ -338,14 +327,7 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
                 prior[j] = pk_max(prior[j], padfloor[j]);
         }
         if (!SLOW) {
-#ifdef SGMX_EXP_NOSTORE
-            if (e[0] == 0x12345678u)
-#endif
-#ifdef SGMX_EXP_SMALLSTORE
-            buf_store_e<RP>(rsE0, (voE + soE) & 0x1FFFFFFu, 0, e); // 32 MB window: stays in L2 / Infinity Cache
-#else
             buf_store_e<RP>(rsE, voE, soE, e);
-#endif
         } else if (t < len) {
             buf_store_e<RP>(rsE, voE, soE, e);
             if (valid) {
@@ -440,28 +422,22 @@ __device__ __forceinline__ void load_pixel(const SumArgs &a, int pair, int y, in
     for (int k = 0; k < 8; k++)
         if (k < a.N) {
             const uint8_t *pk = ep + (size_t)k * a.estride;
-#ifndef SGMX_EXP_NO_NT_LOAD // read once: non-temporal, like the stores that wrote them
-            if (RP == 1) {
+            // read once: non-temporal, like the stores that wrote them
+            if constexpr (RP == 1) {
                 r.ev[k][0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(pk));
-            } else if (RP == 2) {
+            } else if constexpr (RP == 2) {
                 r.ev[k][0] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(pk));
-            } else if (RP == 4) {
+            } else if constexpr (RP == 4) {
                 const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk));
                 r.ev[k][0] = v.x;
-                r.ev[k][(RP + 1) / 2 > 1 ? 1 : 0] = v.y;
+                r.ev[k][1] = v.y;
             } else {
                 const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(pk));
                 r.ev[k][0] = v.x;
-                r.ev[k][(RP + 1) / 2 > 1 ? 1 : 0] = v.y;
-                r.ev[k][(RP + 1) / 2 > 2 ? 2 : 0] = v.z;
-                r.ev[k][(RP + 1) / 2 > 3 ? 3 : 0] = v.w;
+                r.ev[k][1] = v.y;
+                r.ev[k][2] = v.z;
+                r.ev[k][3] = v.w;
             }
-#else
-            if (RP == 1)
-                r.ev[k][0] = *reinterpret_cast<const unsigned short *>(pk);
-            else
-                __builtin_memcpy(r.ev[k], pk, 2 * RP);
-#endif
         }
 }
 
