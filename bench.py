@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--p1", type=int, default=3)
     ap.add_argument("--p2", type=int, default=60)
     ap.add_argument("--paths", type=int, default=8)
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")

@@ -121,6 +121,14 @@ SGMX_API int sgmx_compute_cost_f32_dev(sgmx_ctx *ctx, int n, const float *d_cost
 SGMX_API int sgmx_compute_desc_f32(sgmx_ctx *ctx, const float *desc_left, const float *desc_right, int W, int H, int K,
                                    uint16_t *disp);
 
+/* The callers' pre-filter cv::GaussianBlur(img, img, cv::Size(3,3), sigma) on an 8-bit image
+ * (reconstruction/main/dense_stereo/main.cc:83-85, stereo_eval/main.cc:36-38), host pointers,
+ * src and dst may be the same buffer.  OpenCV is not part of the reference tree and its version is
+ * unpinned: this is the 2.4-era integer path (kernel rounded to 8 fractional bits, int32 row pass,
+ * rounded column pass, reflect-101 border). */
+SGMX_API int sgmx_gaussian_blur3_u8(sgmx_ctx *ctx, const uint8_t *src, int W, int H, int stride_src, double sigma,
+                                    uint8_t *dst, int stride_dst);
+
 /* ---- stage taps (host pointers; for parity tests and debugging) ---- */
 
 /* StereoCosts::census_transform (stereo_costs.cc:36-61): out is (H-2m) x (W-2m) uint32. */

@@ -55,6 +55,8 @@ def lib():
         L.oracle_sgm_census.restype = C.c_int
         L.oracle_sgm_cost_f32.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4
         L.oracle_sgm_cost_f32.restype = C.c_int
+        L.oracle_gaussian3_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_double, u8p]
+        L.oracle_gaussian3_kernel_q8.argtypes = [C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.oracle_fnv_u16.argtypes = [u16p, C.c_size_t]
         L.oracle_fnv_u16.restype = C.c_uint64
         _lib = L
@@ -196,6 +198,20 @@ def sgm_cost_f32(Cvol, P1, P2, num_paths=8, taps=False):
     if taps:
         return dict(disp=disp, S=S, raw=raw, n_undefined=nundef.value)
     return disp
+
+
+def gaussian3(img, sigma):
+    """cv::GaussianBlur(img, img, Size(3,3), sigma) on 8-bit (parity unpinned: OpenCV version)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib().oracle_gaussian3_u8(img, img.shape[1], img.shape[0], img.shape[1], float(sigma), out)
+    return out
+
+
+def gaussian3_kernel_q8(sigma):
+    k0, k1 = C.c_int(), C.c_int()
+    lib().oracle_gaussian3_kernel_q8(float(sigma), C.byref(k0), C.byref(k1))
+    return k0.value, k1.value
 
 
 def fnv_u16(img):

@@ -571,6 +571,55 @@ ORACLE_API int oracle_sgm_cost_f32(const float *C, int w, int h, int D, int P1, 
     return rc;
 }
 
+/* cv::GaussianBlur(img, img, cv::Size(3,3), sigma) on CV_8U, the callers' pre-filter
+ * (dense_stereo/main.cc:83-85, stereo_eval/main.cc:36-38).  OpenCV is not part of the reference
+ * tree and its version is unpinned -> PARITY UNPINNED; restated here is the integer path of the
+ * 2.4-era library the mains were written against: getGaussianKernel(3, sigma, CV_32F)
+ * (t_i = exp(-0.5 x^2 / sigma^2) kept as float, normalised by the float sum), both separable
+ * kernels rounded to 8 fractional bits, the row pass in int32, the column pass rounded by
+ * (v + 2^15) >> 16 and saturated; border = reflect-101. */
+ORACLE_API void oracle_gaussian3_kernel_q8(double sigma, int *k0, int *k1)
+{
+    const double sx = sigma > 0 ? sigma : ((3 - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale = -0.5 / (sx * sx);
+    float c[3];
+    double sum = 0;
+    for (int i = 0; i < 3; i++) {
+        const double x = i - 1.0;
+        c[i] = (float)exp(scale * x * x);
+        sum += c[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < 3; i++)
+        c[i] = (float)(c[i] * sum);
+    *k0 = (int)lrint((double)c[1] * 256.0);
+    *k1 = (int)lrint((double)c[0] * 256.0);
+}
+
+ORACLE_API void oracle_gaussian3_u8(const uint8_t *in, int W, int H, int stride, double sigma, uint8_t *out)
+{
+    int k0, k1;
+    oracle_gaussian3_kernel_q8(sigma, &k0, &k1);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int acc = 0;
+            for (int j = -1; j <= 1; j++) {
+                int yy = y + j;
+                yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+                if (H == 1)
+                    yy = 0;
+                const uint8_t *r = in + (size_t)yy * stride;
+                int xm = x - 1 < 0 ? 1 : x - 1, xp = x + 1 >= W ? W - 2 : x + 1;
+                if (W == 1)
+                    xm = xp = 0;
+                const int row = k1 * (r[xm] + r[xp]) + k0 * r[x];
+                acc += (j == 0 ? k0 : k1) * row;
+            }
+            const int v = (acc + (1 << 15)) >> 16;
+            out[(size_t)y * W + x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+}
+
 /* Checksum SURVEY.md 8c quotes its known answers in: FNV-1a style, one update
  * per uint16 pixel value, h0 = 1469598103934665603, prime 1099511628211. */
 ORACLE_API uint64_t oracle_fnv_u16(const uint16_t *v, size_t n)

@@ -5,6 +5,7 @@
 #include "sgmx_kernels.hpp"
 #include "sgmx_kernels_v2.hpp"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -224,14 +225,14 @@ template <bool F32> void launch_agg(int R, bool first, bool pad, const AggArgs &
 #undef SGMX_DISPATCH
 }
 
-// The 8 (or 4) ordered direction sweeps over n pairs resident in c->d_C.
-int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st)
+// The 8 (or 4) ordered direction sweeps (materialised formulation) over the n cost volumes at Cvol.
+int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st, const void *Cvol)
 {
     const int np = c->prm.num_paths;
     HIPCHK(c, hipMemsetAsync(c->d_BLm, 0, c->bytes_BLm * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
     for (int k = 0; k < np; k++) {
         AggArgs a;
-        a.C = c->d_C;
+        a.C = Cvol;
         a.S = c->d_S;
         a.BL = c->d_BLm;
         a.w = c->w;
@@ -443,7 +444,7 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
                            c->d_cr_dense, w, 0, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
         HIPCHK(c, hipGetLastError());
     }
-    int rc = run_aggregation(c, n, false, st);
+    int rc = run_aggregation(c, n, false, st, c->d_C);
     if (rc)
         return rc;
     rc = run_wta_median(c, n, false, d_disp, st);
@@ -642,16 +643,14 @@ int sgmx_compute_cost_f32_dev(sgmx_ctx *c, int n, const float *d_cost, int W, in
     for (int i = 0; i < n; i += c->prm.max_batch) {
         const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
         const float *src = d_cost + (size_t)i * npix * D;
-        const void *saveC = c->d_C;
-        if (D == c->Dp) {
-            c->d_C = const_cast<float *>(src); // stream the caller's volume in place
-        } else {
+        const void *vol = src; // D == Dp: stream the caller's volume in place
+        if (D != c->Dp) {
             const size_t tot = (size_t)g * npix * c->Dp;
             hipLaunchKernelGGL(repitch_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, D,
                                (float *)c->d_C, c->Dp, (size_t)g * npix, 0.f);
+            vol = c->d_C;
         }
-        rc = run_aggregation(c, g, true, st);
-        c->d_C = const_cast<void *>(saveC);
+        rc = run_aggregation(c, g, true, st, vol);
         if (rc)
             return rc;
         rc = run_wta_median(c, g, true, d_disp + i * npix, st);
@@ -716,7 +715,7 @@ int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc
         const size_t tot = npix * c->Dp;
         hipLaunchKernelGGL(descriptor_cost_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_f,
                            d_f + npix * K, W, K, c->prm.disp_range, c->Dp, (float *)c->d_C, tot);
-        rc = run_aggregation(c, 1, true, st);
+        rc = run_aggregation(c, 1, true, st, c->d_C);
         if (!rc)
             rc = run_wta_median(c, 1, true, c->d_out, st);
         c->last_n = 1;
@@ -729,6 +728,41 @@ int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc
         return rc;
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, SGMX_ERR_HIP, std::string("descriptor path copy/sync: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_gaussian_blur3_u8(sgmx_ctx *c, const uint8_t *src, int W, int H, int stride_src, double sigma, uint8_t *dst,
+                           int stride_dst)
+{
+    if (!c || !src || !dst || W < 1 || H < 1 || stride_src < W || stride_dst < W)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size / pitch");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    // getGaussianKernel(3, sigma, CV_32F), then 8 fractional bits (see include/sgmx.h)
+    const double sx = sigma > 0 ? sigma : ((3 - 1) * 0.5 - 1) * 0.3 + 0.8;
+    float kf[3];
+    double sum = 0;
+    for (int i = 0; i < 3; i++) {
+        const double x = i - 1.0;
+        kf[i] = (float)std::exp(-0.5 / (sx * sx) * x * x);
+        sum += kf[i];
+    }
+    sum = 1. / sum;
+    const int k0 = (int)std::lrint((double)(float)(kf[1] * sum) * 256.0), k1 = (int)std::lrint((double)(float)(kf[0] * sum) * 256.0);
+    uint8_t *d = nullptr;
+    const size_t nb = (size_t)W * H;
+    HIPCHK(c, hipMalloc((void **)&d, 2 * nb));
+    hipStream_t st = c->own_stream;
+    hipError_t e = stride_src == W ? hipMemcpyAsync(d, src, nb, hipMemcpyHostToDevice, st)
+                                   : hipMemcpy2DAsync(d, W, src, stride_src, W, H, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gauss3_u8_kernel, dim3((W + 255) / 256, H, 1), dim3(256), 0, st, d, W, H, k0, k1, d + nb);
+        e = stride_dst == W ? hipMemcpyAsync(dst, d + nb, nb, hipMemcpyDeviceToHost, st)
+                            : hipMemcpy2DAsync(dst, stride_dst, d + nb, W, W, H, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("gaussian blur: ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return SGMX_OK;
 }
 

@@ -740,6 +740,34 @@ __global__ __launch_bounds__(256) void median3_kernel(const uint16_t *__restrict
 }
 
 // ---------------------------------------------------------------------------
+// Caller-side pre-filter cv::GaussianBlur(img, img, Size(3,3), sigma) on 8-bit images
+// (dense_stereo/main.cc:83-85, stereo_eval/main.cc:36-38): separable 3-tap kernel with 8 fractional
+// bits (k0 centre, k1 sides), int32 row pass, (v + 2^15) >> 16 column pass, reflect-101 border.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gauss3_u8_kernel(const uint8_t *__restrict__ in, int W, int H, int k0, int k1,
+                                                        uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W)
+        return;
+    const uint8_t *img = in + (size_t)blockIdx.z * W * H;
+    const int xm = W == 1 ? 0 : (x == 0 ? 1 : x - 1), xp = W == 1 ? 0 : (x == W - 1 ? W - 2 : x + 1);
+    int acc = 0;
+#pragma unroll
+    for (int j = -1; j <= 1; j++) {
+        int yy = y + j;
+        yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+        yy = H == 1 ? 0 : yy;
+        const uint8_t *r = img + (size_t)yy * W;
+        const int row = k1 * ((int)r[xm] + (int)r[xp]) + k0 * (int)r[x];
+        acc += (j == 0 ? k0 : k1) * row;
+    }
+    const int v = (acc + (1 << 15)) >> 16;
+    out[((size_t)blockIdx.z * H + y) * W + x] = (uint8_t)(v > 255 ? 255 : v);
+}
+
+// ---------------------------------------------------------------------------
 // Small helpers: layout conversion for taps / the float input, debug WTA on C,
 // Hamming matrix (core/hamming.c:215-236).
 // ---------------------------------------------------------------------------

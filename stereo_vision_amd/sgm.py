@@ -88,6 +88,18 @@ class Engine:
         return tot, agg.value
 
 
+def _gaussian_blur3(engine, img, sigma):
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise ValueError("gaussian_blur3 wants a single-channel uint8 image")
+    if img.strides[1] != 1:
+        img = np.ascontiguousarray(img)
+    H, W = img.shape
+    out = np.empty((H, W), np.uint8)
+    engine.check(engine.lib.sgmx_gaussian_blur3_u8(engine.h, _ptr(img), W, H, img.strides[0], float(sigma), _ptr(out), W))
+    return out
+
+
 class StereoSGM(Engine):
     """recon::StereoSGM (stereo_sgm.h:53-57), COST_CENSUS build."""
 
@@ -107,6 +119,10 @@ class StereoSGM(Engine):
         self.check(self.lib.sgmx_compute_census_u8(self.h, _ptr(left_img), _ptr(right_img), W, H,
                                                    left_img.strides[0], right_img.strides[0], _ptr(disp), 2 * W))
         return disp
+
+    def gaussian_blur3(self, img, sigma=0.7):
+        """cv::GaussianBlur(img, img, Size(3,3), sigma), the pre-filter of dense_stereo/main.cc:83-85."""
+        return _gaussian_blur3(self, img, sigma)
 
     def compute_batch(self, lefts, rights):
         """(n, H, W) uint8 x2 -> (n, H, W) uint16; what the batch scripts do pair by pair."""

@@ -169,3 +169,28 @@ def test_float_path_matches_integer_path_on_integer_costs(oracle):
         oracle.aggregate_dir_u32(Cu, dx, dy, 3, 17, bu)
         oracle.aggregate_dir_f32(Cf, dx, dy, 3, 17, bf)
         assert np.array_equal(bu.astype(np.float32), bf)
+
+
+def test_gaussian3_against_numpy(oracle):
+    """Caller-side pre-blur (dense_stereo/main.cc:83-85): the C restatement against a direct numpy
+    statement of the same fixed-point arithmetic.  PARITY UNPINNED by the reference (OpenCV is not
+    in its tree and its version is not pinned); sigma = 0.7 gives the taps 54/149/54 (sum 257: the
+    2.4-era integer path rounds the float taps independently)."""
+    assert oracle.gaussian3_kernel_q8(0.7) == (149, 54)
+    assert oracle.gaussian3_kernel_q8(0.0) == oracle.gaussian3_kernel_q8(0.8)  # automatic sigma for ksize 3
+    rng = np.random.default_rng(3)
+    for shape in [(9, 13), (1, 7), (7, 1), (2, 2), (1, 1)]:
+        img = rng.integers(0, 256, size=shape).astype(np.uint8)
+        k0, k1 = oracle.gaussian3_kernel_q8(0.7)
+        pad = img.astype(np.int64)
+        pad = np.pad(pad, ((1, 1) if shape[0] > 1 else (0, 0), (1, 1) if shape[1] > 1 else (0, 0)), mode="reflect")
+        if shape[1] > 1:
+            rows = k1 * (pad[:, :-2] + pad[:, 2:]) + k0 * pad[:, 1:-1]
+        else:
+            rows = (2 * k1 + k0) * pad
+        if shape[0] > 1:
+            acc = k1 * (rows[:-2] + rows[2:]) + k0 * rows[1:-1]
+        else:
+            acc = (2 * k1 + k0) * rows
+        want = np.minimum((acc + (1 << 15)) >> 16, 255).astype(np.uint8)
+        assert np.array_equal(oracle.gaussian3(img, 0.7), want), shape

@@ -235,3 +235,18 @@ def test_float_cost_path(oracle, case):
     assert same >= 0.999
     # pixels whose subpixel value is undefined in the reference (NaN cast) are the only allowed difference
     assert int(np.sum(disp != want["disp"])) <= 9 * want["n_undefined"]
+
+
+# ---------------------------------------------------------------- caller-side pre-filter
+@pytest.mark.parametrize("shape", [(376, 1241), (37, 53), (1, 9), (9, 1), (1, 1), (2, 300)])
+@pytest.mark.parametrize("sigma", [0.7, 0.0, 1.5])
+def test_gaussian_blur3(oracle, shape, sigma):
+    """cv::GaussianBlur(img, img, Size(3,3), sigma) of dense_stereo/main.cc:83-85 (OpenCV arithmetic:
+    parity unpinned by the reference, bit-exact against the oracle's restatement)."""
+    rng = np.random.default_rng(shape[0] * 31 + shape[1])
+    img = rng.integers(0, 256, size=shape).astype(np.uint8)
+    e = make(disp_range=16, window_sz=3)
+    assert np.array_equal(e.gaussian_blur3(img, sigma), oracle.gaussian3(img, sigma))
+    wide = rng.integers(0, 256, size=(shape[0], shape[1] + 5)).astype(np.uint8)
+    view = wide[:, 2:2 + shape[1]]  # row pitch != width
+    assert np.array_equal(e.gaussian_blur3(view, sigma), oracle.gaussian3(np.ascontiguousarray(view), sigma))
