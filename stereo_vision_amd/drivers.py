@@ -92,6 +92,44 @@ def make_output_dirs(out_folder):
     return not existed
 
 
+def read_string_list(filename):
+    """core::FormatHelper::readStringList (core/format_helper.cc:232-245): an OpenCV FileStorage XML
+    file whose first top-level node is a sequence of strings (config_files/kitti_00_lst.xml:1-7).
+    Returns the list, or None where the reference returns false."""
+    import re
+    from xml.sax.saxutils import unescape
+    try:
+        text = open(filename).read()
+    except OSError:
+        return None
+    m = re.search(r"<opencv_storage>(.*)</opencv_storage>", text, re.S)
+    if not m:
+        return None
+    body = re.sub(r"<!--.*?-->", "", m.group(1), flags=re.S)
+    m = re.search(r"<(\w+)[^>]*>(.*?)</\1>", body, re.S)
+    if not m or "<" in m.group(2):
+        return None
+    ent = {"&quot;": '"', "&apos;": "'"}
+    return [unescape(a if a else b, ent) for a, b in re.findall(r'"([^"]*)"|(\S+)', m.group(2))]
+
+
+def read_config_file(filename):
+    """boost::program_options config file as dense_stereo/main.cc:160-166 reads it (unknown keys
+    allowed): `key = value`, `#` comments.  Returns a dict, or None if the file cannot be opened."""
+    try:
+        lines = open(filename).read().splitlines()
+    except OSError:
+        return None
+    kv = {}
+    for line in lines:
+        line = line.split("#", 1)[0]
+        if "=" in line:
+            k, v = line.split("=", 1)
+            if k.strip():
+                kv[k.strip()] = v.strip()
+    return kv
+
+
 # ---------------------------------------------------------------- image I/O and previews
 def read_gray(path):
     from PIL import Image
@@ -111,17 +149,33 @@ def read_png16(path):
 
 
 def to_u8_div256(disp):
-    """img_disp.convertTo(img8, CV_8U, 1.0/256.0) (sgm_single/main.cc:45): round half to even, saturate."""
-    return np.clip(np.rint(disp.astype(np.float64) / 256.0), 0, 255).astype(np.uint8)
+    """img_disp.convertTo(img8, CV_8U, 1.0/256.0) (sgm_single/main.cc:45): float32 product, round half
+    to even, saturate."""
+    return np.clip(np.rint(disp.astype(np.float32) * np.float32(1.0 / 256.0)), 0, 255).astype(np.uint8)
 
 
 def normalize_minmax_u8(img8):
-    """cv::normalize(src, dst, 0, 255, cv::NORM_MINMAX) on CV_8U (sgm_single/main.cc:56)."""
+    """cv::normalize(src, dst, 0, 255, cv::NORM_MINMAX) on CV_8U (sgm_single/main.cc:56): scale and
+    shift in double, applied in float32 (two rounded operations), round half to even."""
     lo, hi = int(img8.min()), int(img8.max())
     if hi == lo:
         return np.zeros_like(img8)
     scale = 255.0 / (hi - lo)
-    return np.clip(np.rint((img8.astype(np.float64) - lo) * scale), 0, 255).astype(np.uint8)
+    t = img8.astype(np.float32) * np.float32(scale)
+    return np.clip(np.rint(t + np.float32(-lo * scale)), 0, 255).astype(np.uint8)
+
+
+def equalize_hist(img8):
+    """cv::equalizeHist on CV_8U (dense_stereo/main.cc:108, stereo_eval/main.cc:55)."""
+    hist = np.bincount(img8.reshape(-1), minlength=256)
+    i = int(np.flatnonzero(hist)[0])
+    if hist[i] == img8.size:
+        return np.full_like(img8, i)
+    scale = np.float32(255.0) / np.float32(img8.size - hist[i])
+    lut = np.zeros(256, np.uint8)
+    csum = np.cumsum(hist[i + 1:]).astype(np.float32)
+    lut[i + 1:] = np.clip(np.rint(csum * scale), 0, 255).astype(np.uint8)
+    return lut[img8]
 
 
 def stem(path):
@@ -155,6 +209,29 @@ def sgm_cnn(left_desc_path, right_desc_path, out_dir, prefix, P1, P2, disp_range
     disp = eng.Compute(left_desc_path, right_desc_path)
     write_outputs(out_dir, prefix, disp)
     return disp
+
+
+def dense_stereo(imagelist, source_folder, output_folder, disp_range=270, window_sz=5, P1=7, P2=60, sigma=0.7, device=0,
+                 write_yml=False):
+    """runDenseStereo (dense_stereo/main.cc:42-118): left/right names alternate in `imagelist`; both
+    images are Gaussian-blurred (:83-85), run through StereoSGM with the mains' hard-coded parameters
+    (:87-97) and saved as output_folder/img/disp_<n>.png (8-bit, saturated, equalised).  Returns the
+    list of disparity maps."""
+    from PIL import Image
+    eng = StereoSGM(StereoSGMParams(disp_range=disp_range, window_sz=window_sz, penalty1=P1, penalty2=P2, device=device))
+    os.makedirs(output_folder + "img", exist_ok=True)
+    os.makedirs(output_folder + "mat", exist_ok=True)
+    out = []
+    for i in range(0, len(imagelist) - 1, 2):
+        left, right = (read_gray(source_folder + imagelist[k]) for k in (i, i + 1))
+        if sigma is not None:
+            left, right = eng.gaussian_blur3(left, sigma), eng.gaussian_blur3(right, sigma)
+        disp = eng.compute(left, right)
+        nm = imagelist[i]
+        tag = nm[9:len(nm) - 4] if len(nm) >= 14 else stem(nm)  # substr(9, size - 13), :106
+        Image.fromarray(equalize_hist(np.minimum(disp, 255).astype(np.uint8))).save(output_folder + "img/disp_" + tag + ".png")
+        out.append(disp)
+    return out
 
 
 # ---------------------------------------------------------------- batch drivers
