@@ -121,6 +121,27 @@ SGMX_API int sgmx_compute_cost_f32_dev(sgmx_ctx *ctx, int n, const float *d_cost
 SGMX_API int sgmx_compute_desc_f32(sgmx_ctx *ctx, const float *desc_left, const float *desc_right, int W, int H, int K,
                                    uint16_t *disp);
 
+/* recon::SGMStereo, the reference's second float pipeline (reconstruction/base/new_sgm/sgm_stereo.{h,cc};
+ * the alternate binary of scripts/run_sgm_batch_cnn.py:7): eight textbook paths (no carry-over between
+ * directions) on the left volume and on the right volume derived from it (sgm_stereo.cc:208-246),
+ * first-minimum WTA with the pipeline's own sub-pixel estimate (:362-402), speckle filter (100 pixels,
+ * difference 2; :413-488), correct / mismatch / occlusion states (:490-531), interpolation (:534-557),
+ * round(256 * d) and a 5x5 median (:79-85).  Uses params.disp_range / penalty1 / penalty2 (penalty1 <
+ * penalty2 as SetSmoothnessCostParameters demands, :16-28; num_paths is ignored, the pipeline has eight);
+ * W >= D and D <= 256 are required.
+ *   _cost_f32: replaces void SGMStereo::Compute(const std::string data_cost_path, cv::Mat*) (sgm_stereo.h:29,
+ *     sgm_stereo.cc:52-56) after LoadDataCostFromFile has read the [H][W][D] float volume (:602-627).
+ *   _desc_f32: replaces void SGMStereo::Compute(left_descriptors_path, right_descriptors_path, cv::Mat*)
+ *     (sgm_stereo.h:26-28, sgm_stereo.cc:38-50) after the two descriptor files are in memory; the data cost
+ *     (:158-181, last valid cost repeated where x < d) is built on the GPU.
+ * disp: H x W uint16, dense. */
+SGMX_API int sgmx_sgmstereo_cost_f32(sgmx_ctx *ctx, const float *cost, int W, int H, int D, int consistency_threshold,
+                                     uint16_t *disp);
+SGMX_API int sgmx_sgmstereo_cost_f32_dev(sgmx_ctx *ctx, int n, const float *d_cost, int W, int H, int D,
+                                         int consistency_threshold, uint16_t *d_disp, void *stream);
+SGMX_API int sgmx_sgmstereo_desc_f32(sgmx_ctx *ctx, const float *desc_left, const float *desc_right, int W, int H, int K,
+                                     int consistency_threshold, uint16_t *disp);
+
 /* The callers' pre-filter cv::GaussianBlur(img, img, cv::Size(3,3), sigma) on an 8-bit image
  * (reconstruction/main/dense_stereo/main.cc:83-85, stereo_eval/main.cc:36-38), host pointers,
  * src and dst may be the same buffer.  OpenCV is not part of the reference tree and its version is
@@ -154,6 +175,12 @@ SGMX_API int sgmx_hamming_matrix_u16(sgmx_ctx *ctx, uint16_t *dis, const uint8_t
  * pointer may be NULL. */
 SGMX_API int sgmx_get_stages_census(sgmx_ctx *ctx, int index, uint8_t *C, uint16_t *S, uint16_t *raw_disp);
 SGMX_API int sgmx_get_stages_f32(sgmx_ctx *ctx, int index, float *S, uint16_t *raw_disp);
+
+/* Stages of volume `index` of the last SGMStereo launch group: summed costs of the left pass (sum_cost_,
+ * sgm_stereo.cc:357), left / right integer disparities after the speckle filter (:62-65, 413), states after
+ * the interpolation ('c', 'm', 'o'; :490-557), the 16-bit image before the median (:79-80). */
+SGMX_API int sgmx_get_stages_sgmstereo(sgmx_ctx *ctx, int index, float *S_left, int32_t *left_disp, int32_t *right_disp,
+                                       uint8_t *states, uint16_t *raw_disp);
 
 /* GetDisparityImage (stereo_sgm.h:243-257): WTA on the raw data cost of pair
  * `index` of the last census launch group, (h+2m) x (w+2m) uint8.  The reference

@@ -18,12 +18,13 @@ u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
 u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
     """Compile liboracle.so (and _ref/ when the reference tree is mounted)."""
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
-            os.path.join(_HERE, "sgm_oracle.c")):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(
+            os.path.getmtime(os.path.join(_HERE, f)) for f in ("sgm_oracle.c", "sgmstereo_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_HAMMING)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -57,6 +58,16 @@ def lib():
         L.oracle_sgm_cost_f32.restype = C.c_int
         L.oracle_gaussian3_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_double, u8p]
         L.oracle_gaussian3_kernel_q8.argtypes = [C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_ns_left_cost_desc.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        L.oracle_ns_right_cost.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
+        L.oracle_ns_right_cost.restype = C.c_int
+        L.oracle_ns_speckle.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.oracle_ns_perform_sgm.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, i32p, C.c_void_p, C.c_void_p]
+        L.oracle_ns_lr_states.argtypes = [i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        L.oracle_ns_interpolate.argtypes = [u8p, f32p, C.c_int, C.c_int]
+        L.oracle_median5_u16.argtypes = [u16p, C.c_int, C.c_int, u16p]
+        L.oracle_ns_compute.argtypes = [f32p] + [C.c_int] * 6 + [u16p] + [C.c_void_p] * 5
+        L.oracle_ns_compute.restype = C.c_int
         L.oracle_fnv_u16.argtypes = [u16p, C.c_size_t]
         L.oracle_fnv_u16.restype = C.c_uint64
         _lib = L
@@ -217,3 +228,82 @@ def gaussian3_kernel_q8(sigma):
 def fnv_u16(img):
     img = np.ascontiguousarray(img, np.uint16)
     return int(lib().oracle_fnv_u16(img.reshape(-1), img.size))
+
+
+# ---------------------------------------------------------------- recon::SGMStereo (new_sgm/sgm_stereo.cc)
+def ns_left_cost_desc(fl, fr, D):
+    fl = np.ascontiguousarray(fl, np.float32)
+    fr = np.ascontiguousarray(fr, np.float32)
+    h, w, K = fl.shape
+    out = np.empty((h, w, D), np.float32)
+    lib().oracle_ns_left_cost_desc(fl, fr, w, h, K, D, out)
+    return out
+
+
+def ns_right_cost(left_cost):
+    left_cost = np.ascontiguousarray(left_cost, np.float32)
+    h, w, D = left_cost.shape
+    out = np.zeros_like(left_cost)
+    if lib().oracle_ns_right_cost(left_cost, w, h, D, out):
+        raise ValueError("SGMStereo needs width >= disparity range")
+    return out
+
+
+def ns_speckle(img, max_size=100, max_diff=2):
+    img = np.ascontiguousarray(img, np.int32).copy()
+    lib().oracle_ns_speckle(img, img.shape[1], img.shape[0], max_size, max_diff)
+    return img
+
+
+def ns_perform_sgm(cost, P1, P2, subpix=True):
+    cost = np.ascontiguousarray(cost, np.float32)
+    h, w, D = cost.shape
+    disp = np.empty((h, w), np.int32)
+    sp = np.empty((h, w), np.float32) if subpix else None
+    S = np.empty((h, w, D), np.float32)
+    lib().oracle_ns_perform_sgm(cost, w, h, D, float(P1), float(P2), disp, sp.ctypes.data if subpix else None, S.ctypes.data)
+    return dict(disp=disp, subpix=sp, S=S)
+
+
+def ns_lr_states(left, right, D, thr):
+    left = np.ascontiguousarray(left, np.int32)
+    right = np.ascontiguousarray(right, np.int32)
+    st = np.empty(left.shape, np.uint8)
+    lib().oracle_ns_lr_states(left, right, left.shape[1], left.shape[0], D, thr, st)
+    return st
+
+
+def ns_interpolate(states, disp):
+    st = np.ascontiguousarray(states, np.uint8).copy()
+    d = np.ascontiguousarray(disp, np.float32).copy()
+    lib().oracle_ns_interpolate(st, d, st.shape[1], st.shape[0])
+    return st, d
+
+
+def median5(img):
+    img = np.ascontiguousarray(img, np.uint16)
+    out = np.empty_like(img)
+    lib().oracle_median5_u16(img, img.shape[1], img.shape[0], out)
+    return out
+
+
+def ns_compute(left_cost, P1, P2, thr=1, taps=False):
+    """recon::SGMStereo::ComputeSGM (sgm_stereo.cc:58-101) on a left data-cost volume."""
+    left_cost = np.ascontiguousarray(left_cost, np.float32)
+    h, w, D = left_cost.shape
+    disp = np.empty((h, w), np.uint16)
+    if not taps:
+        rc = lib().oracle_ns_compute(left_cost, w, h, D, P1, P2, thr, disp, None, None, None, None, None)
+        if rc:
+            raise ValueError("oracle_ns_compute failed (%d): width < D?" % rc)
+        return disp
+    S = np.empty((h, w, D), np.float32)
+    ld = np.empty((h, w), np.int32)
+    rd = np.empty((h, w), np.int32)
+    st = np.empty((h, w), np.uint8)
+    raw = np.empty((h, w), np.uint16)
+    rc = lib().oracle_ns_compute(left_cost, w, h, D, P1, P2, thr, disp, S.ctypes.data, ld.ctypes.data, rd.ctypes.data,
+                                 st.ctypes.data, raw.ctypes.data)
+    if rc:
+        raise ValueError("oracle_ns_compute failed (%d): width < D?" % rc)
+    return dict(disp=disp, S=S, left=ld, right=rd, states=st, raw=raw)

@@ -33,6 +33,10 @@ SYMBOLS = {
     "sgmx_compute_cost_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sgmx_compute_cost_f32_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "sgmx_compute_desc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sgmx_sgmstereo_cost_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sgmx_sgmstereo_cost_f32_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sgmx_sgmstereo_desc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sgmx_get_stages_sgmstereo": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sgmx_gaussian_blur3_u8": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _i]),
     "sgmx_census_u32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sgmx_hamming_volume_u8": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

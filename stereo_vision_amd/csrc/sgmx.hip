@@ -4,6 +4,7 @@
 #include "../../include/sgmx.h"
 #include "sgmx_kernels.hpp"
 #include "sgmx_kernels_v2.hpp"
+#include "sgmx_kernels_ns.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -20,6 +21,9 @@ thread_local std::string g_create_error;
 
 const int DIRS8[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}}; // stereo_sgm.cc:120-122
 const int DIRS4[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
+// recon::SGMStereo (new_sgm/sgm_stereo.cc:283-316,357): the order in which its two raster passes add the paths
+// into sum_cost -- previous pixel of the row, previous row's x-step / x / x+step, forwards then backwards.
+const int DIRS_NS[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
 
 struct ProfRec {
     int cls;
@@ -37,7 +41,7 @@ struct sgmx_ctx {
     // geometry the scratch is currently sized for
     int W = 0, H = 0;          // census: full image; float: volume size
     int w = 0, h = 0, m = 0;   // cropped
-    int mode = 0;              // 0 none, 1 census, 2 float
+    int mode = 0;              // 0 none, 1 census, 2 float, 3 float SGMStereo pipeline
     bool fast = false;         // census path without C / S volumes (sgmx_kernels_v2.hpp): P2 <= 255, D <= 256
     int RP = 4, DpF = 128;     // fast path: packed pairs per lane, padded disparity count 32 * RP
     int wp = 0;                // row pitch of the padded right census image (fast path)
@@ -59,6 +63,11 @@ struct sgmx_ctx {
     size_t bytes_E = 0;         // one pair of one direction
     uint16_t *d_raw = nullptr, *d_out = nullptr;
     size_t bytes_C = 0, bytes_S = 0, bytes_BL = 0;
+    // SGMStereo pipeline (mode 3): right cost volume, integer disparities, labels / region sizes of the
+    // speckle filter, sub-pixel disparities, left/right states
+    float *d_C2 = nullptr, *d_sub = nullptr;
+    int *d_ld = nullptr, *d_rd = nullptr, *d_label = nullptr, *d_size = nullptr;
+    uint8_t *d_states = nullptr;
 
     hipStream_t own_stream = nullptr;
     bool profiling = false;
@@ -88,7 +97,8 @@ int fail(sgmx_ctx *c, int code, const std::string &msg)
 
 void free_scratch(sgmx_ctx *c)
 {
-    void *ptrs[] = {c->d_left, c->d_right, c->d_cl, c->d_cr, c->d_C, c->d_S, c->d_BL, c->d_raw, c->d_out, c->d_E, c->d_SB};
+    void *ptrs[] = {c->d_left, c->d_right, c->d_cl,  c->d_cr, c->d_C,  c->d_S,     c->d_BL,   c->d_raw,   c->d_out,
+                    c->d_E,    c->d_SB,    c->d_C2,  c->d_sub, c->d_ld, c->d_rd,   c->d_label, c->d_size, c->d_states};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -104,6 +114,9 @@ void free_scratch(sgmx_ctx *c)
     c->d_raw = c->d_out = nullptr;
     c->d_E = nullptr;
     c->d_SB = nullptr;
+    c->d_C2 = c->d_sub = nullptr;
+    c->d_ld = c->d_rd = c->d_label = c->d_size = nullptr;
+    c->d_states = nullptr;
     c->mode = 0;
     c->W = c->H = 0;
 }
@@ -151,6 +164,15 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
         HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * B));
         c->d_BLm = c->d_BL;
         c->d_cr_dense = c->d_cr;
+    }
+    if (mode == 3) {
+        HIPCHK(c, hipMalloc((void **)&c->d_C2, c->bytes_C * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_sub, npix * 4 * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_ld, npix * 4 * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_rd, npix * 4 * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_label, npix * 4 * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_size, npix * 4 * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_states, npix * B));
     }
     HIPCHK(c, hipMalloc((void **)&c->d_raw, nfull * 2 * B));
     HIPCHK(c, hipMalloc((void **)&c->d_out, nfull * 2 * B));
@@ -226,11 +248,15 @@ template <bool F32> void launch_agg(int R, bool first, bool pad, const AggArgs &
 }
 
 // The 8 (or 4) ordered direction sweeps (materialised formulation) over the n cost volumes at Cvol.
-int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st, const void *Cvol)
+// `order` != nullptr: eight sweeps in that order, each from an all-zero border ring, i.e. without the
+// reference's carry-over between directions (the textbook start L = C of new_sgm/sgm_stereo.cc:333).
+int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st, const void *Cvol, const int (*order)[2] = nullptr)
 {
-    const int np = c->prm.num_paths;
+    const int np = order ? 8 : c->prm.num_paths;
     HIPCHK(c, hipMemsetAsync(c->d_BLm, 0, c->bytes_BLm * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
     for (int k = 0; k < np; k++) {
+        if (order && k > 0)
+            HIPCHK(c, hipMemsetAsync(c->d_BLm, 0, c->bytes_BLm * n, st));
         AggArgs a;
         a.C = Cvol;
         a.S = c->d_S;
@@ -238,8 +264,8 @@ int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st, const void *Cv
         a.w = c->w;
         a.h = c->h;
         a.D = c->prm.disp_range;
-        a.dx = np == 8 ? DIRS8[k][0] : DIRS4[k][0];
-        a.dy = np == 8 ? DIRS8[k][1] : DIRS4[k][1];
+        a.dx = order ? order[k][0] : (np == 8 ? DIRS8[k][0] : DIRS4[k][0]);
+        a.dy = order ? order[k][1] : (np == 8 ? DIRS8[k][1] : DIRS4[k][1]);
         a.P1 = c->prm.penalty1;
         a.P2 = c->prm.penalty2;
         a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
@@ -450,6 +476,93 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
     rc = run_wta_median(c, n, false, d_disp, st);
     c->last_n = n;
     return rc;
+}
+
+// SpeckleFilter(100, 2, image) of sgm_stereo.cc:413 on n integer disparity images.
+int ns_speckle(sgmx_ctx *c, int n, int *d_img, hipStream_t st)
+{
+    const int w = c->w, h = c->h, npix = w * h;
+    HIPCHK(c, hipMemsetAsync(c->d_size, 0, (size_t)npix * 4 * n, st));
+    hipLaunchKernelGGL(ns_ccl_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, st, d_img, w, h, 2, c->d_label);
+    if (h > 1)
+        hipLaunchKernelGGL(ns_ccl_cols_kernel, dim3((w + 255) / 256, h - 1, n), dim3(256), 0, st, d_img, w, h, 2, c->d_label);
+    hipLaunchKernelGGL(ns_ccl_count_kernel, dim3((npix + 255) / 256, n), dim3(256), 0, st, c->d_label, npix, c->d_size);
+    hipLaunchKernelGGL(ns_ccl_apply_kernel, dim3((npix + 255) / 256, n), dim3(256), 0, st, d_img, c->d_label, npix, c->d_size,
+                       100);
+    HIPCHK(c, hipGetLastError());
+    return SGMX_OK;
+}
+
+template <int R> void launch_ns_wta(dim3 grid, hipStream_t st, const float *S, int w, int h, int D, int *disp, float *sub)
+{
+    hipLaunchKernelGGL(ns_wta_kernel<R>, grid, dim3(256), 0, st, S, w, h, D, disp, sub);
+}
+
+// recon::SGMStereo::ComputeSGM (new_sgm/sgm_stereo.cc:58-101) on n <= max_batch left data-cost volumes of
+// pitch Dp, device resident.  The right-image pass runs first so that d_S holds the left sums afterwards
+// (for the tap); the two passes are independent.
+int ns_group(sgmx_ctx *c, int n, const float *left, int thr, uint16_t *d_disp, hipStream_t st)
+{
+    const int w = c->w, h = c->h, D = c->prm.disp_range;
+    const size_t npix = (size_t)w * h;
+    const dim3 rows(h, n);
+    auto wta = [&](int *disp, float *sub) {
+        ProfScope ps(c, SGMX_K_WTA, st);
+        if (c->R == 1)
+            launch_ns_wta<1>(rows, st, (const float *)c->d_S, w, h, D, disp, sub);
+        else if (c->R == 2)
+            launch_ns_wta<2>(rows, st, (const float *)c->d_S, w, h, D, disp, sub);
+        else
+            launch_ns_wta<4>(rows, st, (const float *)c->d_S, w, h, D, disp, sub);
+    };
+    {
+        const size_t tot = (size_t)n * npix * c->Dp;
+        ProfScope ps(c, SGMX_K_HAMMING, st); // data-cost class
+        hipLaunchKernelGGL(ns_right_cost_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, left, w, D, c->Dp,
+                           c->d_C2, tot);
+        HIPCHK(c, hipGetLastError());
+    }
+    int rc = run_aggregation(c, n, true, st, c->d_C2, DIRS_NS);
+    if (rc)
+        return rc;
+    wta(c->d_rd, nullptr);
+    if ((rc = ns_speckle(c, n, c->d_rd, st)))
+        return rc;
+    if ((rc = run_aggregation(c, n, true, st, left, DIRS_NS)))
+        return rc;
+    wta(c->d_ld, c->d_sub);
+    if ((rc = ns_speckle(c, n, c->d_ld, st)))
+        return rc;
+    hipLaunchKernelGGL(ns_lr_kernel, dim3((w + 255) / 256, h, n), dim3(256), 0, st, c->d_ld, c->d_rd, w, h, D, thr,
+                       c->d_states);
+    hipLaunchKernelGGL(ns_interpolate_kernel, dim3((h + 3) / 4, n), dim3(256), 0, st, c->d_states, c->d_sub, w, h);
+    hipLaunchKernelGGL(ns_scale_kernel, dim3((unsigned)((npix * n + 255) / 256)), dim3(256), 0, st, c->d_sub, npix * n,
+                       c->d_raw);
+    {
+        ProfScope ps(c, SGMX_K_MEDIAN, st);
+        hipLaunchKernelGGL(median5_kernel, dim3((w + 255) / 256, h, n), dim3(256), 0, st, c->d_raw, w, h, d_disp);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->last_n = n;
+    return SGMX_OK;
+}
+
+int ns_check(sgmx_ctx *c, int W, int H, int D, int thr)
+{
+    if (!c)
+        return SGMX_ERR_INVALID_ARG;
+    if (D != c->prm.disp_range)
+        return fail(c, SGMX_ERR_INVALID_ARG, "D differs from params.disp_range");
+    // SetSmoothnessCostParameters / SetConsistencyThreshold (sgm_stereo.cc:16-36) throw on these
+    if (c->prm.penalty1 >= c->prm.penalty2)
+        return fail(c, SGMX_ERR_INVALID_ARG, "SGMStereo: penalty1 must be smaller than penalty2");
+    if (thr < 0)
+        return fail(c, SGMX_ERR_INVALID_ARG, "SGMStereo: consistency threshold must not be negative");
+    if (D > 256)
+        return fail(c, SGMX_ERR_INVALID_ARG, "SGMStereo: disparity range above 256 overflows the 16-bit output (256 * d)");
+    if (W < D)
+        return fail(c, SGMX_ERR_INVALID_ARG, "SGMStereo: width smaller than the disparity range (the reference indexes out of bounds)");
+    return SGMX_OK;
 }
 
 int check_size(sgmx_ctx *c, int W, int H, bool census)
@@ -713,7 +826,7 @@ int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc
         e = hipMemcpyAsync(d_f + npix * K, desc_right, nb, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         const size_t tot = npix * c->Dp;
-        hipLaunchKernelGGL(descriptor_cost_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_f,
+        hipLaunchKernelGGL(descriptor_cost_kernel<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_f,
                            d_f + npix * K, W, K, c->prm.disp_range, c->Dp, (float *)c->d_C, tot);
         rc = run_aggregation(c, 1, true, st, c->d_C);
         if (!rc)
@@ -728,6 +841,104 @@ int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc
         return rc;
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, SGMX_ERR_HIP, std::string("descriptor path copy/sync: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_sgmstereo_cost_f32_dev(sgmx_ctx *c, int n, const float *d_cost, int W, int H, int D, int consistency_threshold,
+                                uint16_t *d_disp, void *stream)
+{
+    if (!c || !d_cost || !d_disp || n < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or n < 1");
+    int rc = ns_check(c, W, H, D, consistency_threshold);
+    if (!rc)
+        rc = check_size(c, W, H, false);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    if ((rc = ensure_scratch(c, 3, W, H)))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)W * H;
+    for (int i = 0; i < n; i += c->prm.max_batch) {
+        const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
+        const float *src = d_cost + (size_t)i * npix * D;
+        if (D != c->Dp) { // D == Dp: the caller's volume is streamed in place
+            const size_t tot = (size_t)g * npix * c->Dp;
+            hipLaunchKernelGGL(repitch_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, D,
+                               (float *)c->d_C, c->Dp, (size_t)g * npix, 0.f);
+            src = (const float *)c->d_C;
+        }
+        if ((rc = ns_group(c, g, src, consistency_threshold, d_disp + i * npix, st)))
+            return rc;
+    }
+    return SGMX_OK;
+}
+
+int sgmx_sgmstereo_cost_f32(sgmx_ctx *c, const float *cost, int W, int H, int D, int consistency_threshold, uint16_t *disp)
+{
+    if (!c || !cost || !disp)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer");
+    int rc = ns_check(c, W, H, D, consistency_threshold);
+    if (!rc)
+        rc = check_size(c, W, H, false);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    const size_t npix = (size_t)W * H;
+    float *d_in = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_in, npix * D * 4));
+    hipStream_t st = c->own_stream;
+    hipError_t e = hipMemcpyAsync(d_in, cost, npix * D * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = ensure_scratch(c, 3, W, H);
+        if (!rc)
+            rc = sgmx_sgmstereo_cost_f32_dev(c, 1, d_in, W, H, D, consistency_threshold, c->d_out, st);
+        if (!rc)
+            e = hipMemcpyAsync(disp, c->d_out, npix * 2, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_in);
+    if (rc)
+        return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("SGMStereo copy/sync: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_sgmstereo_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc_right, int W, int H, int K,
+                            int consistency_threshold, uint16_t *disp)
+{
+    if (!c || !desc_left || !desc_right || !disp || K < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or K < 1");
+    int rc = ns_check(c, W, H, c->prm.disp_range, consistency_threshold);
+    if (!rc)
+        rc = check_size(c, W, H, false);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    if ((rc = ensure_scratch(c, 3, W, H)))
+        return rc;
+    const size_t npix = (size_t)W * H, nb = npix * K * sizeof(float);
+    float *d_f = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_f, 2 * nb));
+    hipStream_t st = c->own_stream;
+    hipError_t e = hipMemcpyAsync(d_f, desc_left, nb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_f + npix * K, desc_right, nb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const size_t tot = npix * c->Dp;
+        hipLaunchKernelGGL(descriptor_cost_kernel<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_f,
+                           d_f + npix * K, W, K, c->prm.disp_range, c->Dp, (float *)c->d_C, tot);
+        rc = ns_group(c, 1, (const float *)c->d_C, consistency_threshold, c->d_out, st);
+        if (!rc)
+            e = hipMemcpyAsync(disp, c->d_out, npix * 2, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_f);
+    if (rc)
+        return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("SGMStereo descriptor path copy/sync: ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return SGMX_OK;
 }
 
@@ -944,6 +1155,22 @@ int sgmx_get_stages_census(sgmx_ctx *c, int index, uint8_t *C, uint16_t *S, uint
 int sgmx_get_stages_f32(sgmx_ctx *c, int index, float *S, uint16_t *raw_disp)
 {
     return get_stages(c, 2, index, nullptr, S, raw_disp);
+}
+
+int sgmx_get_stages_sgmstereo(sgmx_ctx *c, int index, float *S_left, int32_t *left_disp, int32_t *right_disp,
+                              uint8_t *states, uint16_t *raw_disp)
+{
+    int rc = get_stages(c, 3, index, nullptr, S_left, raw_disp);
+    if (rc)
+        return rc;
+    const size_t npix = (size_t)c->w * c->h;
+    if (left_disp)
+        HIPCHK(c, hipMemcpy(left_disp, c->d_ld + index * npix, npix * 4, hipMemcpyDeviceToHost));
+    if (right_disp)
+        HIPCHK(c, hipMemcpy(right_disp, c->d_rd + index * npix, npix * 4, hipMemcpyDeviceToHost));
+    if (states)
+        HIPCHK(c, hipMemcpy(states, c->d_states + index * npix, npix, hipMemcpyDeviceToHost));
+    return SGMX_OK;
 }
 
 int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)

@@ -801,6 +801,9 @@ __global__ __launch_bounds__(256) void data_cost_wta_kernel(const uint8_t *__res
 // Descriptor data cost (sgm.cc:76-84, initialisation sgm.cc:55): C[y][x][d] = ||fL[y][x] - fR[y][x-d]||_2
 // for x >= d, FLT_MAX otherwise; pad disparities d >= D get 0.  One thread per voxel, the K
 // differences summed left to right in float32 (Eigen's own reduction order is build dependent).
+// REPLICATE: recon::SGMStereo's variant (new_sgm/sgm_stereo.cc:158-181), which repeats the cost of
+// the last valid disparity d = x where x < d instead of FLT_MAX (:174).
+template <bool REPLICATE>
 __global__ __launch_bounds__(256) void descriptor_cost_kernel(const float *__restrict__ fl, const float *__restrict__ fr,
                                                               int w, int K, int D, int Dp, float *__restrict__ C,
                                                               size_t total)
@@ -809,14 +812,15 @@ __global__ __launch_bounds__(256) void descriptor_cost_kernel(const float *__res
     if (t >= total)
         return;
     const size_t pix = t / Dp;
-    const int d = (int)(t - pix * Dp);
+    int d = (int)(t - pix * Dp);
     const int x = (int)(pix % (size_t)w);
     float v;
     if (d >= D) {
         v = 0.f;
-    } else if (d > x) {
+    } else if (d > x && !REPLICATE) {
         v = 3.402823466e+38f;
     } else {
+        d = d > x ? x : d;
         const float *a = fl + pix * K, *b = fr + (pix - d) * K;
         float s = 0.f;
         for (int k = 0; k < K; k++) {

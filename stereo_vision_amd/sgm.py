@@ -238,3 +238,95 @@ class SGM(Engine):
         raw = np.empty((H, W), np.uint16)
         self.check(self.lib.sgmx_get_stages_f32(self.h, index, _ptr(S), _ptr(raw)))
         return dict(S=S, raw=raw)
+
+
+def load_data_cost(path):
+    """SGMStereo::LoadDataCostFromFile (new_sgm/sgm_stereo.cc:602-627): int32 dims (= 3), uint64
+    size[3] = {H, W, D}, float32[H][W][D] -- the same container as the descriptor files."""
+    return load_representation(path)
+
+
+class SGMStereo:
+    """recon::SGMStereo (reconstruction/base/new_sgm/sgm_stereo.h:11-81): the reference's second float
+    pipeline -- eight textbook paths on the left and on the derived right volume, speckle filter,
+    correct / mismatch / occlusion states, interpolation, 5x5 median.  Same method names and defaults
+    (kDisparityRange 256, kP1 3, kP2 40, kConsistencyThreshold 1; sgm_stereo.h:17-22).  The disparity
+    range of a data-cost volume comes with the volume (sgm_stereo.cc:613-615), so the sgmx context is
+    made on first use and remade when the range or the penalties change."""
+
+    def __init__(self, device=0, max_batch=1):
+        self.disp_range, self.P1, self.P2, self.consistency_threshold = 256, 3, 40, 1
+        self.device, self.max_batch = device, max_batch
+        self._eng = None
+
+    def SetSmoothnessCostParameters(self, P1, P2):
+        """sgm_stereo.cc:16-28 (std::invalid_argument there)."""
+        if P1 < 0 or P2 < 0:
+            raise ValueError("smoothness penalty value is less than zero")
+        if P1 >= P2:
+            raise ValueError("small value of smoothness penalty must be smaller than large penalty value")
+        self.P1, self.P2 = int(P1), int(P2)
+
+    def SetConsistencyThreshold(self, consistency_threshold):
+        """sgm_stereo.cc:30-36."""
+        if consistency_threshold < 0:
+            raise ValueError("threshold for LR consistency must be positive")
+        self.consistency_threshold = int(consistency_threshold)
+
+    def _engine(self, D):
+        key = (D, self.P1, self.P2)
+        if self._eng is None or self._eng[0] != key:
+            if self._eng is not None:
+                self._eng[1].close()
+            self._eng = (key, Engine(StereoSGMParams(disp_range=D, window_sz=1, penalty1=self.P1, penalty2=self.P2,
+                                                     device=self.device, max_batch=self.max_batch)))
+        return self._eng[1]
+
+    def compute_cost(self, cost):
+        """(H, W, D) float32 left data-cost volume -> (H, W) uint16 (ComputeSGM, sgm_stereo.cc:58-101)."""
+        cost = np.ascontiguousarray(cost, np.float32)
+        H, W, D = cost.shape
+        e = self._engine(D)
+        disp = np.empty((H, W), np.uint16)
+        e.check(e.lib.sgmx_sgmstereo_cost_f32(e.h, _ptr(cost), W, H, D, self.consistency_threshold, _ptr(disp)))
+        return disp
+
+    def compute_cost_device(self, d_cost, d_disp, n, W, H, D, stream=0):
+        e = self._engine(D)
+        e.check(e.lib.sgmx_sgmstereo_cost_f32_dev(e.h, n, d_cost, W, H, D, self.consistency_threshold, d_disp, stream))
+
+    def compute_desc(self, desc_left, desc_right):
+        """(H, W, K) float32 descriptor tensors -> (H, W) uint16 (Compute(left, right), sgm_stereo.cc:38-50)."""
+        fl = np.ascontiguousarray(desc_left, np.float32)
+        fr = np.ascontiguousarray(desc_right, np.float32)
+        if fl.shape != fr.shape or fl.ndim != 3:
+            raise ValueError("sizes of left and right images are different")  # sgm_stereo.cc:112-114
+        H, W, K = fl.shape
+        e = self._engine(self.disp_range)
+        disp = np.empty((H, W), np.uint16)
+        e.check(e.lib.sgmx_sgmstereo_desc_f32(e.h, _ptr(fl), _ptr(fr), W, H, K, self.consistency_threshold, _ptr(disp)))
+        return disp
+
+    def Compute(self, *paths):
+        """Compute(left_descriptors_path, right_descriptors_path) or Compute(data_cost_path)
+        (sgm_stereo.h:26-29); returns the CV_16U disparity the reference writes through its pointer."""
+        if len(paths) == 2:
+            return self.compute_desc(load_representation(paths[0]), load_representation(paths[1]))
+        if len(paths) == 1:
+            return self.compute_cost(load_data_cost(paths[0]))
+        raise TypeError("Compute(left_desc_path, right_desc_path) or Compute(data_cost_path)")
+
+    def stages(self, H, W, index=0):
+        e = self._eng[1]
+        D = self._eng[0][0]
+        S = np.empty((H, W, D), np.float32)
+        ld = np.empty((H, W), np.int32)
+        rd = np.empty((H, W), np.int32)
+        st = np.empty((H, W), np.uint8)
+        raw = np.empty((H, W), np.uint16)
+        e.check(e.lib.sgmx_get_stages_sgmstereo(e.h, index, _ptr(S), _ptr(ld), _ptr(rd), _ptr(st), _ptr(raw)))
+        return dict(S=S, left=ld, right=rd, states=st, raw=raw)
+
+    @property
+    def engine(self):
+        return self._eng[1] if self._eng else None
