@@ -22,6 +22,19 @@ dt = timeit(lambda: e.compute_cost_device(C.data_ptr(), out.data_ptr(), B, W, H,
 print("float volume 1241x376x128, B=%d: %.2f ms per step, %.1f volumes/s, alg %.2f TB/s (96 B/voxel)" % (B, dt * 1e3, B / dt, 96 * H * W * D * B / dt / 1e12))
 e.close(); del C
 
+# SGMStereo pipeline (new_sgm) on a float volume, KITTI size
+B = 4
+C = (torch.rand((B, H, W, D), device="cuda") * 4).contiguous()
+out = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
+e2 = sv.SGMStereo(max_batch=B)
+e2.SetSmoothnessCostParameters(3, 60)
+dt = timeit(lambda: e2.compute_cost_device(C.data_ptr(), out.data_ptr(), B, W, H, D, 0))
+e2.engine.set_profiling(True)
+e2.compute_cost_device(C.data_ptr(), out.data_ptr(), B, W, H, D, 0)
+print("SGMStereo float volume 1241x376x128, B=%d: %.2f ms per step, %.1f volumes/s; kernel classes (ms): %s" %
+      (B, dt * 1e3, B / dt, {k: round(v[0], 3) for k, v in e2.engine.kernel_stats().items()}))
+del C, e2
+
 # 4K census D=256
 H, W, D = 2160, 3840, 256
 for B in (1, 2, 4, 8):

@@ -6,6 +6,7 @@
 //   recon::StereoSGMParams, recon::StereoSGM::compute   stereo_sgm.h:15-21, 53-57; stereo_sgm.cc:15-188
 //   recon::SGMParams,       recon::SGM::Compute         sgm.h:18-23, 61-65;      sgm.cc:14-174
 //   SGM::LoadRepresentationFromFile                     sgm.h:378-410
+//   recon::SGMStereo::{Compute,Set...}                  new_sgm/sgm_stereo.h:24-34; sgm_stereo.cc:16-101
 //
 // The image type is a template parameter with cv::Mat's member names (rows, cols, data, step,
 // type(), create(rows, cols, type)), so the same code serves cv::Mat where OpenCV is installed
@@ -287,6 +288,95 @@ class SGM {
 
   private:
     SGMParams params_;
+    sgmx::Context ctx_;
+};
+
+// recon::SGMStereo (reconstruction/base/new_sgm/sgm_stereo.h:11-81): the second float pipeline.  Same
+// methods and defaults (kDisparityRange 256, kP1 3, kP2 40, kConsistencyThreshold 1; sgm_stereo.h:17-22).
+// The disparity range of a data-cost volume comes from its file (sgm_stereo.cc:613-615), so the sgmx
+// context is made on first use and remade when the range or the penalties change.
+class SGMStereo {
+  public:
+    explicit SGMStereo(int device = 0) : device_(device) {}
+
+    // sgm_stereo.cc:16-28
+    void SetSmoothnessCostParameters(const double P1, const double P2)
+    {
+        if (P1 < 0 || P2 < 0)
+            throw std::invalid_argument("[SGMStereo::SetSmoothnessCostParameters] smoothness penalty value is less than zero");
+        if (P1 >= P2)
+            throw std::invalid_argument("[SGMStereo::SetSmoothnessCostParameters] small value of smoothness penalty must be "
+                                        "smaller than large penalty value");
+        P1_ = (int)P1;
+        P2_ = (int)P2;
+    }
+    // sgm_stereo.cc:30-36
+    void SetConsistencyThreshold(const int consistency_threshold)
+    {
+        if (consistency_threshold < 0)
+            throw std::invalid_argument("[SGMStereo::SetConsistencyThreshold] threshold for LR consistency must be positive");
+        consistency_threshold_ = consistency_threshold;
+    }
+
+    // void Compute(left_descriptors_path, right_descriptors_path, cv::Mat* disparity) (sgm_stereo.cc:38-50)
+    template <class MatT>
+    void Compute(const std::string left_descriptors_path, const std::string right_descriptors_path, MatT *disparity)
+    {
+        sgmx::DescriptorTensor l, r;
+        sgmx::LoadRepresentationFromFile(left_descriptors_path, &l);
+        sgmx::LoadRepresentationFromFile(right_descriptors_path, &r);
+        if (l.H != r.H || l.W != r.W || l.K != r.K)
+            throw std::invalid_argument("[SGMStereo::setImageSize] sizes of left and right images are different");
+        sgmx::Context &c = context(disp_range_);
+        std::vector<uint16_t> dense((size_t)l.H * l.W);
+        c.check(sgmx_sgmstereo_desc_f32(c.get(), l.v.data(), r.v.data(), (int)l.W, (int)l.H, (int)l.K, consistency_threshold_,
+                                        dense.data()),
+                "sgmx_sgmstereo_desc_f32");
+        fill(disparity, dense, (int)l.W, (int)l.H);
+    }
+
+    // void Compute(data_cost_path, cv::Mat* disparity) (sgm_stereo.cc:52-56): the file is the [H][W][D]
+    // float left data cost in the descriptor container (LoadDataCostFromFile, :602-627).
+    template <class MatT> void Compute(const std::string data_cost_path, MatT *disparity)
+    {
+        sgmx::DescriptorTensor t;
+        sgmx::LoadRepresentationFromFile(data_cost_path, &t);
+        sgmx::Context &c = context((int)t.K);
+        std::vector<uint16_t> dense((size_t)t.H * t.W);
+        c.check(sgmx_sgmstereo_cost_f32(c.get(), t.v.data(), (int)t.W, (int)t.H, (int)t.K, consistency_threshold_, dense.data()),
+                "sgmx_sgmstereo_cost_f32");
+        fill(disparity, dense, (int)t.W, (int)t.H);
+    }
+
+  private:
+    sgmx::Context &context(int D)
+    {
+        if (!ctx_.get() || D != have_D_ || P1_ != have_P1_ || P2_ != have_P2_) {
+            sgmx_params q;
+            std::memset(&q, 0, sizeof(q));
+            q.disp_range = D;
+            q.window_sz = 1;
+            q.penalty1 = P1_;
+            q.penalty2 = P2_;
+            q.device = device_;
+            ctx_.open(q);
+            have_D_ = D;
+            have_P1_ = P1_;
+            have_P2_ = P2_;
+        }
+        return ctx_;
+    }
+    template <class MatT> static void fill(MatT *disparity, const std::vector<uint16_t> &dense, int W, int H)
+    {
+        disparity->create(H, W, sgmx::MAT_16U);
+        for (int y = 0; y < H; y++)
+            std::memcpy(disparity->data + (size_t)y * (size_t)disparity->step, dense.data() + (size_t)y * W,
+                        (size_t)W * sizeof(uint16_t));
+    }
+
+    int device_;
+    int disp_range_ = 256, P1_ = 3, P2_ = 40, consistency_threshold_ = 1;
+    int have_D_ = 0, have_P1_ = 0, have_P2_ = 0;
     sgmx::Context ctx_;
 };
 

@@ -202,6 +202,8 @@ def test_usage_errors_exit_1_like_the_reference():
     for prog, n in [("sgm_single", 3), ("sgm_cnn", 5), ("stereo_eval", 1), ("sgm_batch", 0)]:
         r = run(prog, *(["x"] * n))
         assert r.returncode == 1 and "usage" in r.stderr
+    r = run("sgm", "x", "y")  # new_sgm/sgm_stereo_main.cc:152-161 prints the usage and returns 0
+    assert r.returncode == 0 and "usage: ./sgm data_cost_path out_folder P1 P2 consistency_threshold" in r.stderr
     r = run("sgm_single", "l", "r", "o", "three", "60")
     assert r.returncode == 2 and "integer" in r.stderr
 
@@ -236,5 +238,7 @@ def test_adapter_header_compiles_standalone(tmp_path):
                    "  recon::StereoSGMParams p; p.disp_range = 128; p.window_sz = 5; p.penalty1 = 3; p.penalty2 = 60;\n"
                    "  recon::StereoSGM sgm(p); sgm.compute(l, r, d);\n"
                    "  recon::SGMParams q; q.disp_range = 255; q.penalty1 = 3; q.penalty2 = 60;\n"
-                   '  recon::SGM s(q); sgmx::Mat m = s.Compute("a", "b"); (void)m; }\n')
+                   '  recon::SGM s(q); sgmx::Mat m = s.Compute("a", "b"); (void)m;\n'
+                   '  recon::SGMStereo t; t.SetSmoothnessCostParameters(3, 40); t.SetConsistencyThreshold(1);\n'
+                   '  t.Compute("cost.bin", &d); t.Compute("l.bin", "r.bin", &d); }\n')
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])

@@ -165,3 +165,31 @@ def test_sgm_batch_binary_cnn(oracle, tmp_path):
     run("sgm_batch", "cnn", tmp_path, 3, 60, "--disp-range", 32)
     for pre, w in want.items():
         assert np.mean(drivers.read_png16(str(tmp_path / "depth" / "disparities" / (pre + ".png"))) == w) >= 0.999
+
+
+def test_sgm_binary_new_sgm_pipeline(oracle, tmp_path):
+    """`sgm` (new_sgm/sgm_stereo_main.cc): the data-cost-file form and the descriptor form, output names
+    and 8-bit preview as the reference's main derives them."""
+    from test_sgmstereo_oracle import smooth_volume
+    out = tmp_path / "out"
+    drivers.make_output_dirs(str(out))
+    C, _ = smooth_volume(3, 16, 100, 24)
+    sv.save_representation(str(tmp_path / "000003_10_cost.bin"), C)
+    run("sgm", tmp_path / "000003_10_cost.bin", out, 3, 40, 1)
+    want = oracle.ns_compute(C, 3, 40, 1)
+    got = drivers.read_png16(str(out / "disparities" / "000003_10.png"))
+    assert np.array_equal(got, want)
+    m8 = np.minimum(255, np.floor(want / 256.0 + 0.5)).astype(np.uint8)  # std::round: half away from zero
+    assert np.array_equal(np.array(Image.open(out / "norm_hist" / "000003_10.png")), drivers.normalize_minmax_u8(m8))
+    rng = np.random.default_rng(2)
+    base = rng.standard_normal((8, 270, 4)).astype(np.float32)
+    fl, fr = np.ascontiguousarray(base[:, 6:]), np.ascontiguousarray(base[:, :264])
+    sv.save_representation(str(tmp_path / "000004_10_left.bin"), fl)
+    sv.save_representation(str(tmp_path / "000004_10_right.bin"), fr)
+    run("sgm", tmp_path / "000004_10_left.bin", tmp_path / "000004_10_right.bin", out, 3, 60, 1)
+    want = oracle.ns_compute(oracle.ns_left_cost_desc(fl, fr, 256), 3, 60, 1)
+    assert np.array_equal(drivers.read_png16(str(out / "disparities" / "000004_10.png")), want)
+    # P1 >= P2 is std::invalid_argument in the reference (sgm_stereo.cc:21-24)
+    r = subprocess.run([os.path.join(BIN, "sgm"), str(tmp_path / "000003_10_cost.bin"), str(out), "40", "3", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "smoothness penalty" in r.stderr
