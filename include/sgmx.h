@@ -142,6 +142,23 @@ SGMX_API int sgmx_sgmstereo_cost_f32_dev(sgmx_ctx *ctx, int n, const float *d_co
 SGMX_API int sgmx_sgmstereo_desc_f32(sgmx_ctx *ctx, const float *desc_left, const float *desc_right, int W, int H, int K,
                                      int consistency_threshold, uint16_t *disp);
 
+/* The KITTI stereo evaluation the batch scripts' outputs go through (reconstruction/evaluation): n result
+ * maps and their two ground-truth maps (non-occluded, all), all in the 16-bit on-disk format (value = 256 *
+ * d, 0 = invalid; io_disp.h:220-243), host pointers, dense.  Per image, as the loop body of eval()
+ * (evaluate_stereo.cc:158-175): D_ipol = interpolateBackground(D_orig) (io_disp.h:108-186), then
+ * disparityErrorsOutlier and disparityErrorsAverage (evaluate_stereo.cc:21-119) against both ground truths.
+ * errors: n x 26 floats = noc_out[11], occ_out[11], noc_avg[2], occ_avg[2].  ipol (optional): D_ipol as
+ * D_ipol.write stores it.  A ground truth without a valid pixel is an error (the reference throws). */
+SGMX_API int sgmx_kitti_eval_u16(sgmx_ctx *ctx, int n, const uint16_t *disp, const uint16_t *gt_noc, const uint16_t *gt_occ,
+                                 int W, int H, float *errors, uint16_t *ipol);
+
+/* CalculateDepthImage (reconstruction/main/create_rgbd_dataset/main.cc:12-27) on a 16-bit disparity image as
+ * compute returns it: d = value / 256 (:93); depth = round(100 * focal * baseline / d) centimetres where
+ * d >= 1, else 0 (calib[0], calib[4] at :13-14).  Host pointers, dense.  SGMX_ERR_RANGE when a depth
+ * reaches 65536 (the reference throws, :22). */
+SGMX_API int sgmx_depth_from_disparity_u16(sgmx_ctx *ctx, const uint16_t *disp, int W, int H, double focal, double baseline,
+                                           uint16_t *depth);
+
 /* The callers' pre-filter cv::GaussianBlur(img, img, cv::Size(3,3), sigma) on an 8-bit image
  * (reconstruction/main/dense_stereo/main.cc:83-85, stereo_eval/main.cc:36-38), host pointers,
  * src and dst may be the same buffer.  OpenCV is not part of the reference tree and its version is

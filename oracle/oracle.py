@@ -68,6 +68,11 @@ def lib():
         L.oracle_median5_u16.argtypes = [u16p, C.c_int, C.c_int, u16p]
         L.oracle_ns_compute.argtypes = [f32p] + [C.c_int] * 6 + [u16p] + [C.c_void_p] * 5
         L.oracle_ns_compute.restype = C.c_int
+        L.oracle_kitti_interpolate_background.argtypes = [f32p, C.c_int, C.c_int]
+        L.oracle_kitti_eval_image.argtypes = [u16p, u16p, u16p, C.c_int, C.c_int, f32p, C.c_void_p]
+        L.oracle_kitti_eval_image.restype = C.c_int
+        L.oracle_depth_image.argtypes = [u16p, C.c_int, C.c_int, C.c_double, C.c_double, u16p]
+        L.oracle_depth_image.restype = C.c_int
         L.oracle_fnv_u16.argtypes = [u16p, C.c_size_t]
         L.oracle_fnv_u16.restype = C.c_uint64
         _lib = L
@@ -307,3 +312,30 @@ def ns_compute(left_cost, P1, P2, thr=1, taps=False):
     if rc:
         raise ValueError("oracle_ns_compute failed (%d): width < D?" % rc)
     return dict(disp=disp, S=S, left=ld, right=rd, states=st, raw=raw)
+
+
+# ---------------------------------------------------------------- KITTI stereo evaluation (reconstruction/evaluation)
+def kitti_interpolate_background(d):
+    """DisparityImage::interpolateBackground (io_disp.h:108-186) on a float map, -1 = invalid."""
+    d = np.ascontiguousarray(d, np.float32).copy()
+    lib().oracle_kitti_interpolate_background(d, d.shape[1], d.shape[0])
+    return d
+
+
+def kitti_eval_image(disp, gt_noc, gt_occ, want_ipol=False):
+    """One image of evaluate_stereo.cc:158-175: 26 floats (noc_out[11], occ_out[11], noc_avg[2], occ_avg[2])."""
+    disp, gt_noc, gt_occ = (np.ascontiguousarray(a, np.uint16) for a in (disp, gt_noc, gt_occ))
+    out = np.empty(26, np.float32)
+    ip = np.empty_like(disp) if want_ipol else None
+    rc = lib().oracle_kitti_eval_image(disp, gt_noc, gt_occ, disp.shape[1], disp.shape[0], out,
+                                       ip.ctypes.data if want_ipol else None)
+    if rc:
+        raise ValueError("ground truth holds no valid pixel (the reference throws)")
+    return (out, ip) if want_ipol else out
+
+
+def depth_image(disp, f, b):
+    """CalculateDepthImage (create_rgbd_dataset/main.cc:12-27); None where the reference throws."""
+    disp = np.ascontiguousarray(disp, np.uint16)
+    out = np.empty_like(disp)
+    return None if lib().oracle_depth_image(disp, disp.shape[1], disp.shape[0], float(f), float(b), out) else out

@@ -389,3 +389,186 @@ ORACLE_API int oracle_ns_compute(const float *left_cost, int w, int h, int D, in
     free(raw);
     return rc;
 }
+
+/* ------------------------------------------------------------------ */
+/* KITTI stereo evaluation (reconstruction/evaluation)  */
+/* ------------------------------------------------------------------ */
+
+/* io_disp.h:220-232 readDisparityMap: 16-bit gray value 0 = invalid (-1), else value / 256.0. */
+ORACLE_API void oracle_kitti_read(const uint16_t *png, size_t n, float *data)
+{
+    for (size_t i = 0; i < n; i++)
+        data[i] = png[i] == 0 ? -1.f : (float)(((float)png[i]) / 256.0);
+}
+
+/* io_disp.h:234-243 writeDisparityMap: (uint16_t)max(d * 256.0, 1.0) for valid pixels, 0 otherwise. */
+ORACLE_API void oracle_kitti_write(const float *data, size_t n, uint16_t *png)
+{
+    for (size_t i = 0; i < n; i++) {
+        const double s = data[i] * 256.0;
+        png[i] = data[i] >= 0 ? (uint16_t)(s > 1.0 ? s : 1.0) : 0;
+    }
+}
+
+/* io_disp.h:108-186 interpolateBackground, literal: per row, gaps between two valid pixels take the
+ * smaller of the two, then the row is extrapolated to the left and to the right; then every column
+ * is extrapolated to the top and to the bottom. */
+ORACLE_API void oracle_kitti_interpolate_background(float *d, int width, int height)
+{
+#define VALID(u, v) (d[(size_t)(v) * width + (u)] >= 0)
+#define AT(u, v) d[(size_t)(v) * width + (u)]
+    for (int v = 0; v < height; v++) {
+        int count = 0;
+        for (int u = 0; u < width; u++) {
+            if (VALID(u, v)) {
+                if (count >= 1) {
+                    const int u1 = u - count, u2 = u - 1;
+                    if (u1 > 0 && u2 < width - 1) {
+                        const float a = AT(u1 - 1, v), b = AT(u2 + 1, v);
+                        const float ip = b < a ? b : a; /* std::min(a, b) */
+                        for (int uc = u1; uc <= u2; uc++)
+                            AT(uc, v) = ip;
+                    }
+                }
+                count = 0;
+            } else {
+                count++;
+            }
+        }
+        for (int u = 0; u < width; u++)
+            if (VALID(u, v)) {
+                for (int u2 = 0; u2 < u; u2++)
+                    AT(u2, v) = AT(u, v);
+                break;
+            }
+        for (int u = width - 1; u >= 0; u--)
+            if (VALID(u, v)) {
+                for (int u2 = u + 1; u2 <= width - 1; u2++)
+                    AT(u2, v) = AT(u, v);
+                break;
+            }
+    }
+    for (int u = 0; u < width; u++) {
+        for (int v = 0; v < height; v++)
+            if (VALID(u, v)) {
+                for (int v2 = 0; v2 < v; v2++)
+                    AT(u, v2) = AT(u, v);
+                break;
+            }
+        for (int v = height - 1; v >= 0; v--)
+            if (VALID(u, v)) {
+                for (int v2 = v + 1; v2 <= height - 1; v2++)
+                    AT(u, v2) = AT(u, v);
+                break;
+            }
+    }
+#undef VALID
+#undef AT
+}
+
+/* evaluate_stereo.cc:21-77 disparityErrorsOutlier: errors[2i] = share of ground-truth pixels whose
+ * error exceeds i+1 pixels, errors[2i+1] the same over pixels the result also holds, errors[10] the
+ * density; float counters and float divisions, pixels visited column by column.  Returns 1 where
+ * the reference throws (no valid ground-truth pixel). */
+ORACLE_API int oracle_kitti_errors_outlier(const float *gt, const float *orig, const float *ipol, int width, int height,
+                                           float *errors /* 11 */)
+{
+    for (int i = 0; i < 11; i++)
+        errors[i] = 0;
+    int num_pixels = 0, num_pixels_result = 0;
+    for (int u = 0; u < width; u++)
+        for (int v = 0; v < height; v++) {
+            const size_t k = (size_t)v * width + u;
+            if (gt[k] >= 0) {
+                const float d_err = fabsf(gt[k] - ipol[k]);
+                for (int i = 0; i < 5; i++)
+                    if (d_err > (float)(i + 1))
+                        errors[i * 2]++;
+                num_pixels++;
+                if (orig[k] >= 0) {
+                    for (int i = 0; i < 5; i++)
+                        if (d_err > (float)(i + 1))
+                            errors[i * 2 + 1]++;
+                    num_pixels_result++;
+                }
+            }
+        }
+    if (num_pixels == 0)
+        return 1;
+    const float np = (float)num_pixels > 1.0f ? (float)num_pixels : 1.0f;
+    const float nr = (float)num_pixels_result > 1.0f ? (float)num_pixels_result : 1.0f;
+    for (int i = 0; i < 10; i += 2)
+        errors[i] /= np;
+    if (num_pixels_result > 0)
+        for (int i = 1; i < 10; i += 2)
+            errors[i] /= nr;
+    errors[10] = (float)num_pixels_result / np;
+    return 0;
+}
+
+/* evaluate_stereo.cc:79-119 disparityErrorsAverage: float sums of the absolute error in column-major
+ * pixel order, over ground-truth pixels and over those the result also holds. */
+ORACLE_API void oracle_kitti_errors_average(const float *gt, const float *orig, const float *ipol, int width, int height,
+                                            float *errors /* 2 */)
+{
+    errors[0] = errors[1] = 0;
+    int num_pixels = 0, num_pixels_result = 0;
+    for (int u = 0; u < width; u++)
+        for (int v = 0; v < height; v++) {
+            const size_t k = (size_t)v * width + u;
+            if (gt[k] >= 0) {
+                const float d_err = fabsf(gt[k] - ipol[k]);
+                errors[0] += d_err;
+                num_pixels++;
+                if (orig[k] >= 0) {
+                    errors[1] += d_err;
+                    num_pixels_result++;
+                }
+            }
+        }
+    errors[0] /= (float)num_pixels > 1.0f ? (float)num_pixels : 1.0f;
+    errors[1] /= (float)num_pixels_result > 1.0f ? (float)num_pixels_result : 1.0f;
+}
+
+/* One image of the loop in eval() (evaluate_stereo.cc:158-175): result and the two ground-truth maps
+ * as 16-bit images; out = noc_out[11], occ_out[11], noc_avg[2], occ_avg[2]; ipol_png (optional) =
+ * D_ipol as D_ipol.write would store it.  Returns 1 where the reference throws. */
+ORACLE_API int oracle_kitti_eval_image(const uint16_t *disp, const uint16_t *gt_noc, const uint16_t *gt_occ, int width,
+                                       int height, float *out /* 26 */, uint16_t *ipol_png)
+{
+    const size_t n = (size_t)width * height;
+    float *orig = malloc(n * 4), *ipol = malloc(n * 4), *noc = malloc(n * 4), *occ = malloc(n * 4);
+    oracle_kitti_read(disp, n, orig);
+    memcpy(ipol, orig, n * 4);
+    oracle_kitti_interpolate_background(ipol, width, height);
+    oracle_kitti_read(gt_noc, n, noc);
+    oracle_kitti_read(gt_occ, n, occ);
+    int rc = oracle_kitti_errors_outlier(noc, orig, ipol, width, height, out);
+    rc |= oracle_kitti_errors_outlier(occ, orig, ipol, width, height, out + 11);
+    oracle_kitti_errors_average(noc, orig, ipol, width, height, out + 22);
+    oracle_kitti_errors_average(occ, orig, ipol, width, height, out + 24);
+    if (ipol_png)
+        oracle_kitti_write(ipol, n, ipol_png);
+    free(orig);
+    free(ipol);
+    free(noc);
+    free(occ);
+    return rc;
+}
+
+/* reconstruction/main/create_rgbd_dataset/main.cc:12-27 CalculateDepthImage on the 16-bit disparity
+ * (converted to CV_64F with 1/256 at :93).  Returns 1 where the reference throws (z >= 65536). */
+ORACLE_API int oracle_depth_image(const uint16_t *disp, int W, int H, double f, double b, uint16_t *depth)
+{
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        const double d = disp[i] * (1.0 / 256.0);
+        depth[i] = 0;
+        if (d >= 1.0) {
+            const double z = 100.0 * f * b / d;
+            if (z >= 65536)
+                return 1;
+            depth[i] = (uint16_t)round(z);
+        }
+    }
+    return 0;
+}

@@ -37,6 +37,8 @@ SYMBOLS = {
     "sgmx_sgmstereo_cost_f32_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sgmx_sgmstereo_desc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sgmx_get_stages_sgmstereo": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sgmx_kitti_eval_u16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sgmx_depth_from_disparity_u16": (_i, [_vp, _vp, _i, _i, C.c_double, C.c_double, _vp]),
     "sgmx_gaussian_blur3_u8": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _i]),
     "sgmx_census_u32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sgmx_hamming_volume_u8": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

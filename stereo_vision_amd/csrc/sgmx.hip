@@ -5,6 +5,7 @@
 #include "sgmx_kernels.hpp"
 #include "sgmx_kernels_v2.hpp"
 #include "sgmx_kernels_ns.hpp"
+#include "sgmx_kernels_eval.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -939,6 +940,91 @@ int sgmx_sgmstereo_desc_f32(sgmx_ctx *c, const float *desc_left, const float *de
         return rc;
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, SGMX_ERR_HIP, std::string("SGMStereo descriptor path copy/sync: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_kitti_eval_u16(sgmx_ctx *c, int n, const uint16_t *disp, const uint16_t *gt_noc, const uint16_t *gt_occ, int W,
+                        int H, float *errors, uint16_t *ipol)
+{
+    if (!c || !disp || !gt_noc || !gt_occ || !errors || n < 1 || W < 1 || H < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
+    if ((size_t)W * H >= (size_t)1 << 30)
+        return fail(c, SGMX_ERR_INVALID_ARG, "image too large");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    const size_t npix = (size_t)W * H;
+    const int chunk = n < 64 ? n : 64; // images per launch group
+    uint16_t *d_u16 = nullptr; // disp | gt_noc | gt_occ | ipol as 16-bit
+    float *d_ip = nullptr, *d_err = nullptr;
+    hipError_t e = hipMalloc((void **)&d_u16, npix * 2 * 4 * chunk);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_ip, npix * 4 * chunk);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_err, sizeof(float) * 26 * chunk);
+    hipStream_t st = c->own_stream;
+    for (int i = 0; i < n && e == hipSuccess; i += chunk) {
+        const int g = n - i < chunk ? n - i : chunk;
+        const size_t gb = npix * 2 * g;
+        uint16_t *d_d = d_u16, *d_n = d_u16 + npix * chunk, *d_o = d_u16 + 2 * npix * chunk, *d_w = d_u16 + 3 * npix * chunk;
+        e = hipMemcpyAsync(d_d, disp + i * npix, gb, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d_n, gt_noc + i * npix, gb, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d_o, gt_occ + i * npix, gb, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess)
+            break;
+        hipLaunchKernelGGL(kitti_rows_kernel, dim3((H + 3) / 4, g), dim3(256), 0, st, d_d, W, H, d_ip);
+        hipLaunchKernelGGL(kitti_cols_kernel, dim3((W + 255) / 256, g), dim3(256), 0, st, d_ip, W, H);
+        hipLaunchKernelGGL(kitti_errors_kernel, dim3(g), dim3(256), 0, st, d_d, d_ip, d_n, d_o, W, H, d_err);
+        if (ipol)
+            hipLaunchKernelGGL(kitti_write_kernel, dim3((unsigned)((npix * g + 255) / 256)), dim3(256), 0, st, d_ip, npix * g, d_w);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(errors + (size_t)i * 26, d_err, sizeof(float) * 26 * g, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && ipol)
+            e = hipMemcpyAsync(ipol + i * npix, d_w, gb, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(d_u16);
+    (void)hipFree(d_ip);
+    (void)hipFree(d_err);
+    if (e != hipSuccess)
+        return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP, std::string("KITTI evaluation: ") + hipGetErrorString(e));
+    for (int i = 0; i < n; i++)
+        if (errors[(size_t)i * 26] < 0.f || errors[(size_t)i * 26 + 11] < 0.f)
+            return fail(c, SGMX_ERR_INVALID_ARG, "KITTI evaluation: ground truth " + std::to_string(i) + " holds no valid pixel");
+    return SGMX_OK;
+}
+
+int sgmx_depth_from_disparity_u16(sgmx_ctx *c, const uint16_t *disp, int W, int H, double focal, double baseline,
+                                  uint16_t *depth)
+{
+    if (!c || !disp || !depth || W < 1 || H < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    const size_t n = (size_t)W * H;
+    uint16_t *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, n * 4 + 16));
+    int *flag = reinterpret_cast<int *>(d + 2 * n + (n & 1)); // 4-byte aligned behind the two images
+    hipStream_t st = c->own_stream;
+    int over = 0;
+    hipError_t e = hipMemcpyAsync(d, disp, n * 2, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(flag, 0, 4, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(depth_from_disparity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, n, focal,
+                           baseline, d + n, flag);
+        e = hipMemcpyAsync(depth, d + n, n * 2, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&over, flag, 4, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("depth image: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    if (over)
+        return fail(c, SGMX_ERR_RANGE, "depth image: a depth of 65536 cm or more does not fit 16 bits (the reference throws)");
     return SGMX_OK;
 }
 

@@ -124,6 +124,14 @@ class StereoSGM(Engine):
         """cv::GaussianBlur(img, img, Size(3,3), sigma), the pre-filter of dense_stereo/main.cc:83-85."""
         return _gaussian_blur3(self, img, sigma)
 
+    def depth_image(self, disp, focal, baseline):
+        """CalculateDepthImage (create_rgbd_dataset/main.cc:12-27): 16-bit disparity -> depth in cm."""
+        disp = np.ascontiguousarray(disp, np.uint16)
+        H, W = disp.shape
+        out = np.empty((H, W), np.uint16)
+        self.check(self.lib.sgmx_depth_from_disparity_u16(self.h, _ptr(disp), W, H, float(focal), float(baseline), _ptr(out)))
+        return out
+
     def compute_batch(self, lefts, rights):
         """(n, H, W) uint8 x2 -> (n, H, W) uint16; what the batch scripts do pair by pair."""
         lefts = np.ascontiguousarray(lefts, np.uint8)

@@ -250,3 +250,18 @@ def test_gaussian_blur3(oracle, shape, sigma):
     wide = rng.integers(0, 256, size=(shape[0], shape[1] + 5)).astype(np.uint8)
     view = wide[:, 2:2 + shape[1]]  # row pitch != width
     assert np.array_equal(e.gaussian_blur3(view, sigma), oracle.gaussian3(np.ascontiguousarray(view), sigma))
+
+
+def test_depth_from_disparity(oracle):
+    """CalculateDepthImage of create_rgbd_dataset/main.cc:12-27 (KITTI-like focal length and baseline)."""
+    rng = np.random.default_rng(3)
+    disp = rng.integers(0, 120 * 256, size=(37, 91)).astype(np.uint16)
+    disp[disp < 3 * 256] = 0
+    disp[0, :4] = [255, 256, 257, 768]  # d < 1 stays 0; d = 1 is the first converted value
+    e = make(disp_range=16, window_sz=3)
+    want = oracle.depth_image(disp, 721.5, 0.54)
+    assert want is not None and np.array_equal(e.depth_image(disp, 721.5, 0.54), want)
+    assert want[0, 0] == 0 and want[0, 1] == round(100 * 721.5 * 0.54)
+    assert oracle.depth_image(disp, 7215.0, 0.54) is None
+    with pytest.raises(sv.SgmxError):
+        e.depth_image(disp, 7215.0, 0.54)  # 100 f b / d >= 65536: the reference throws
