@@ -55,6 +55,10 @@ struct sgmx_ctx {
 
     // device scratch (sized for max_batch pairs)
     uint8_t *d_left = nullptr, *d_right = nullptr; // staged inputs for the host entry points
+    uint8_t *d_left2 = nullptr, *d_right2 = nullptr; // second staging set of the pipelined batch entry point
+    uint16_t *d_out2 = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     u32 *d_cl = nullptr, *d_cr = nullptr;
     void *d_C = nullptr;   // uint8 or float, pitch Dp
     void *d_S = nullptr;   // uint16 or float, pitch Dp
@@ -99,7 +103,8 @@ int fail(sgmx_ctx *c, int code, const std::string &msg)
 void free_scratch(sgmx_ctx *c)
 {
     void *ptrs[] = {c->d_left, c->d_right, c->d_cl,  c->d_cr, c->d_C,  c->d_S,     c->d_BL,   c->d_raw,   c->d_out,
-                    c->d_E,    c->d_SB,    c->d_C2,  c->d_sub, c->d_ld, c->d_rd,   c->d_label, c->d_size, c->d_states};
+                    c->d_E,    c->d_SB,    c->d_C2,  c->d_sub, c->d_ld, c->d_rd,   c->d_label, c->d_size, c->d_states,
+                    c->d_left2, c->d_right2, c->d_out2};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -110,6 +115,8 @@ void free_scratch(sgmx_ctx *c)
     c->d_cr_dense = nullptr;
     c->d_BLm = nullptr;
     c->d_left = c->d_right = nullptr;
+    c->d_left2 = c->d_right2 = nullptr;
+    c->d_out2 = nullptr;
     c->d_cl = c->d_cr = nullptr;
     c->d_C = c->d_S = c->d_BL = nullptr;
     c->d_raw = c->d_out = nullptr;
@@ -143,6 +150,9 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
     if (mode == 1) {
         HIPCHK(c, hipMalloc((void **)&c->d_left, nfull * B));
         HIPCHK(c, hipMalloc((void **)&c->d_right, nfull * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_left2, nfull * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_right2, nfull * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_out2, nfull * 2 * B));
         HIPCHK(c, hipMalloc((void **)&c->d_cl, npix * 4 * B));
         HIPCHK(c, hipMalloc((void **)&c->d_cr, (size_t)c->wp * h * 4 * B));
         HIPCHK(c, hipMemset(c->d_cr, 0, (size_t)c->wp * h * 4 * B)); // the padding columns are never written again
@@ -315,10 +325,13 @@ int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t s
     return SGMX_OK;
 }
 
-template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
-                                   uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a)
+#ifndef SGMX_PF_H
+#define SGMX_PF_H 0
+#endif
+template <int RP, int PF>
+void launch_agg3_pf(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr, uint8_t *E, uint16_t *BL,
+                    uint16_t *SB, const Agg2Args &a)
 {
-    constexpr int PF = RP == 8 ? 2 : 4; // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
     if (first) {
         if (pad)
             hipLaunchKernelGGL((aggregate3_kernel<RP, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
@@ -330,6 +343,17 @@ template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t 
         else
             hipLaunchKernelGGL((aggregate3_kernel<RP, false, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
     }
+}
+
+template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
+                                   uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a)
+{
+    constexpr int PF = RP == 8 ? 2 : 4; // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
+    constexpr int PFH = SGMX_PF_H ? SGMX_PF_H : PF;
+    if (PFH != PF && a.dy == 0)
+        launch_agg3_pf<RP, PFH>(first, pad, grid, st, cl, cr, E, BL, SB, a);
+    else
+        launch_agg3_pf<RP, PF>(first, pad, grid, st, cl, cr, E, BL, SB, a);
 }
 
 SumArgs sum_args(const sgmx_ctx *c)
@@ -615,8 +639,11 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
         0x7FFFLL + p.penalty1 > 65535)
         return fail(nullptr, SGMX_ERR_RANGE, "penalties too large for uint16 path costs (need 9180 + 8*P2 <= 65535)");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(nullptr, SGMX_ERR_NO_DEVICE, "no HIP device visible; sgmx has no CPU fallback");
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev <= 0)
+        return fail(nullptr, SGMX_ERR_NO_DEVICE,
+                    std::string("no HIP device visible; sgmx has no CPU fallback") +
+                        (de != hipSuccess ? std::string(" (hipGetDeviceCount: ") + hipGetErrorString(de) + ")" : std::string()));
     if (p.device < 0 || p.device >= ndev)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "device ordinal out of range");
     sgmx_ctx *c = new (std::nothrow) sgmx_ctx();
@@ -629,9 +656,15 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->small_n = (p.flags & SGMX_FLAG_NO_SMALL_GROUPS) ? 0 : 3; // measured crossover at KITTI size: between 3 and 4 pairs
     c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : 8));
     c->DpF = 32 * c->RP;
-    if (hipSetDevice(p.device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
-        delete c;
-        return fail(nullptr, SGMX_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
+    bool ok = hipSetDevice(p.device) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess &&
+              hipStreamCreate(&c->copy_stream) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++)
+        ok = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        sgmx_destroy(c);
+        return fail(nullptr, SGMX_ERR_HIP, "hipSetDevice / stream or event creation failed");
     }
     *out = c;
     return SGMX_OK;
@@ -648,6 +681,12 @@ void sgmx_destroy(sgmx_ctx *ctx)
         (void)hipEventDestroy(r.b);
     }
     free_scratch(ctx);
+    for (int i = 0; i < 2; i++)
+        for (hipEvent_t ev : {ctx->ev_in[i], ctx->ev_done[i], ctx->ev_out[i]})
+            if (ev)
+                (void)hipEventDestroy(ev);
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -688,18 +727,62 @@ int sgmx_compute_census_u8_batch(sgmx_ctx *c, int n, const uint8_t *left, const 
     rc = ensure_scratch(c, 1, W, H);
     if (rc)
         return rc;
-    hipStream_t st = c->own_stream;
+    // Launch groups are pipelined over two staging sets: while group g computes on the compute stream,
+    // the copy stream brings in group g+1 and takes out group g-1 (the scratch volumes are shared, so the
+    // groups themselves run one after the other).
+    hipStream_t st = c->own_stream, cs = c->copy_stream;
     const size_t nfull = (size_t)W * H;
-    for (int i = 0; i < n; i += c->prm.max_batch) {
-        const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
-        HIPCHK(c, hipMemcpyAsync(c->d_left, left + i * nfull, nfull * g, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->d_right, right + i * nfull, nfull * g, hipMemcpyHostToDevice, st));
-        rc = census_group(c, g, c->d_left, c->d_right, c->d_out, st);
+    const int B = c->prm.max_batch, G = (n + B - 1) / B;
+    uint8_t *dl[2] = {c->d_left, c->d_left2}, *dr[2] = {c->d_right, c->d_right2};
+    uint16_t *dout[2] = {c->d_out, c->d_out2};
+    auto count = [&](int g) { return n - g * B < B ? n - g * B : B; };
+    auto copy_in = [&](int g) -> hipError_t {
+        const int s = g & 1;
+        hipError_t e = hipMemcpyAsync(dl[s], left + (size_t)g * B * nfull, nfull * count(g), hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(dr[s], right + (size_t)g * B * nfull, nfull * count(g), hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess)
+            e = hipEventRecord(c->ev_in[s], cs);
+        return e;
+    };
+    auto copy_out = [&](int g) -> hipError_t {
+        const int s = g & 1;
+        hipError_t e = hipStreamWaitEvent(cs, c->ev_done[s], 0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(disp + (size_t)g * B * nfull, dout[s], nfull * 2 * count(g), hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess)
+            e = hipEventRecord(c->ev_out[s], cs);
+        return e;
+    };
+    hipError_t e = copy_in(0);
+    for (int g = 0; g < G && e == hipSuccess && rc == SGMX_OK; g++) {
+        const int s = g & 1;
+        e = hipStreamWaitEvent(st, c->ev_in[s], 0);
+        if (e == hipSuccess && g >= 2)
+            e = hipStreamWaitEvent(st, c->ev_out[s], 0); // group g-2 has left this set's output buffer
+        if (e != hipSuccess)
+            break;
+        rc = census_group(c, count(g), dl[s], dr[s], dout[s], st);
         if (rc)
-            return rc;
-        HIPCHK(c, hipMemcpyAsync(disp + i * nfull, c->d_out, nfull * 2 * g, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+            break;
+        e = hipEventRecord(c->ev_done[s], st);
+        if (e == hipSuccess && g + 1 < G) {
+            if (g >= 1)
+                e = hipStreamWaitEvent(cs, c->ev_done[s ^ 1], 0); // group g-1 has read the other set's inputs
+            if (e == hipSuccess)
+                e = copy_in(g + 1);
+        }
+        if (e == hipSuccess && g >= 1)
+            e = copy_out(g - 1);
     }
+    if (e == hipSuccess && rc == SGMX_OK)
+        e = copy_out(G - 1);
+    const hipError_t e1 = hipStreamSynchronize(st), e2 = hipStreamSynchronize(cs);
+    if (rc)
+        return rc;
+    if (e != hipSuccess || e1 != hipSuccess || e2 != hipSuccess)
+        return fail(c, SGMX_ERR_HIP, std::string("batch copy / sync: ") +
+                                         hipGetErrorString(e != hipSuccess ? e : (e1 != hipSuccess ? e1 : e2)));
     return SGMX_OK;
 }
 
@@ -1006,7 +1089,7 @@ int sgmx_depth_from_disparity_u16(sgmx_ctx *c, const uint16_t *disp, int W, int 
     const size_t n = (size_t)W * H;
     uint16_t *d = nullptr;
     HIPCHK(c, hipMalloc((void **)&d, n * 4 + 16));
-    int *flag = reinterpret_cast<int *>(d + 2 * n + (n & 1)); // 4-byte aligned behind the two images
+    int *flag = reinterpret_cast<int *>(d + 2 * n); // behind the two images: byte offset 4 n
     hipStream_t st = c->own_stream;
     int over = 0;
     hipError_t e = hipMemcpyAsync(d, disp, n * 2, hipMemcpyHostToDevice, st);

@@ -123,3 +123,13 @@ def test_errors():
         e.compute_cost(np.zeros((4, 8, 16), np.float32))  # width < D
     with pytest.raises(sv.SgmxError):
         e.compute_cost(np.zeros((2, 400, 300), np.float32))  # D > 256 overflows 16 bits
+
+
+def test_kitti_size_volume(oracle):
+    """BASELINE configuration 4 through the SGMStereo pipeline at full size (1241 x 376, D = 128): every
+    stage against the oracle (about 10 s of CPU)."""
+    H, W, D = 376, 1241, 128
+    C, _ = smooth_volume(5, H, W, D)
+    e = sv.SGMStereo()
+    e.SetSmoothnessCostParameters(3, 60)
+    check(oracle, e, C, 3, 60, 1)
