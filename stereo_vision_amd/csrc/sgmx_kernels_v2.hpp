@@ -17,16 +17,21 @@
 //   C + S formulation that the algorithmic-byte model counts.  With that the sweeps are bound by
 //   VALU issue (4 cycles per wave64 instruction), so the mapping minimises instructions per pixel:
 //
-// Lane mapping ("16 x RP x 2"): a pixel's Dp = 32 RP disparities live in ONE 16-lane DPP row; a
-// wave carries 4 pixels -- 4 different paths of the same direction, walked in lock step.  Lane q
-// of a row holds RP packed uint16 pairs, register j = ( d = RP q + j , d = Dp/2 + RP q + j ).
-//   - d-1 / d+1 of register j are registers j-1 / j+1 of the same lane (no shuffles); only
-//     register 0 / RP-1 need the neighbour lane: one row rotate each plus a fix-up of the lane
-//     where the low half wraps into the high half.
-//   - min over d is RP-1 packed mins, a half swap, and 4 row-rotate DPP mins that leave the
-//     minimum in every lane of the row (both halves), no scalar round trip.
+// Lane mapping ("16 x RP x 2, mirrored"): a pixel's Dp = 32 RP disparities live in ONE 16-lane DPP
+// row; a wave carries 4 pixels -- 4 different paths of the same direction, walked in lock step.
+// Lane q of a row holds RP packed uint16 pairs, register j = ( d = RP q + j , d = Dp-1 - (RP q + j) ):
+// the low halves run upwards from 0, the high halves downwards from Dp-1.
+//   - The recurrence only needs min(L[d-1], L[d+1]); with the mirrored halves that is
+//     pk_min(register j-1, register j+1) for BOTH halves (d-1 of the low half and d+1 of the high
+//     half sit in register j-1, and vice versa), no shuffles inside a lane.
+//   - "Register -1" is lane q-1's top register (one row_shr DPP; lane 0 has no neighbour on either
+//     half and keeps an INF pair).  "Register RP" is lane q+1's register 0 (one row_shl DPP); in
+//     lane 15 the two halves of the top register (d = Dp/2-1, Dp/2) are each other's neighbours, so
+//     it keeps its own top register with the halves swapped.
+//   - min over d is RP-1 packed mins, a min of the two halves, and 4 row-rotate DPP mins that leave
+//     the minimum in every lane of the row, no scalar round trip.
 //
-// Memory layouts private to this path (d_lo = RP q + j, d_hi = Dp/2 + RP q + j):
+// Memory layouts private to this path (d_lo = RP q + j, d_hi = Dp-1 - d_lo):
 //   census left  uint32 [h][w];  census right uint32 [h][wp], wp = Dp + w, pixel x in column Dp + x
 //     (so the RP words censR[x-d] of a lane window are one contiguous in-row load for every x >= 0;
 //      costs with d > x are forced to 255, stereo_sgm.cc:43)
@@ -91,47 +96,65 @@ template <> __device__ __forceinline__ void buf_load_win<8>(__amdgpu_buffer_rsrc
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; o[4] = u.x; o[5] = u.y; o[6] = u.z; o[7] = u.w;
 }
 
-// RP packed pairs (each half <= 255) -> 2 RP bytes [lo0, hi0, lo1, hi1, ...]
-template <int RP> __device__ __forceinline__ void buf_store_e(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[RP]);
-template <> __device__ __forceinline__ void buf_store_e<1>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[1])
+// RP packed pairs (each half <= 255) -> 2 RP bytes [lo0, hi0, lo1, hi1, ...] in NW = ceil(RP/2) dwords
+template <int RP> __device__ __forceinline__ void pack_e(const u32 (&e)[RP], u32 (&v)[(RP + 1) / 2])
 {
-    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)__builtin_amdgcn_perm(0u, e[0], 0x0c0c0200u), rs, voff, soff, E_STORE_AUX);
+    if constexpr (RP == 1) {
+        v[0] = __builtin_amdgcn_perm(0u, e[0], 0x0c0c0200u);
+    } else {
+#pragma unroll
+        for (int m = 0; m < RP / 2; m++)
+            v[m] = __builtin_amdgcn_perm(e[2 * m + 1], e[2 * m], 0x06040200u);
+    }
 }
-template <> __device__ __forceinline__ void buf_store_e<2>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[2])
+template <int RP>
+__device__ __forceinline__ void buf_store_ev(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&v)[(RP + 1) / 2])
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(e[1], e[0], 0x06040200u), rs, voff, soff, E_STORE_AUX);
+    if constexpr (RP == 1) {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v[0], rs, voff, soff, E_STORE_AUX);
+    } else if constexpr (RP == 2) {
+        __builtin_amdgcn_raw_buffer_store_b32(v[0], rs, voff, soff, E_STORE_AUX);
+    } else if constexpr (RP == 4) {
+        u32x2 t;
+        t.x = v[0]; t.y = v[1];
+        __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, E_STORE_AUX);
+    } else {
+        u32x4 t;
+        t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, E_STORE_AUX);
+    }
 }
-template <> __device__ __forceinline__ void buf_store_e<4>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[4])
+// the same bytes back (accumulating sweeps), non-temporal like the stores
+template <int RP>
+__device__ __forceinline__ void buf_load_ev(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&v)[(RP + 1) / 2])
 {
-    u32x2 v;
-    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u);
-    v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, soff, E_STORE_AUX);
-}
-template <> __device__ __forceinline__ void buf_store_e<8>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const u32 (&e)[8])
-{
-    u32x4 v;
-    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u);
-    v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
-    v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u);
-    v.w = __builtin_amdgcn_perm(e[7], e[6], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, E_STORE_AUX);
+    if constexpr (RP == 1) {
+        v[0] = (u32)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, E_STORE_AUX);
+    } else if constexpr (RP == 2) {
+        v[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, E_STORE_AUX);
+    } else if constexpr (RP == 4) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, E_STORE_AUX);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, E_STORE_AUX);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
 }
 
-// Hamming costs of a lane: wl[i] = censR[x - RP q - (RP-1) + i] (register j = RP-1-i, low half),
-// wh[i] the same Dp/2 columns further left (high half).  tl = x - RP q: with MASK the halves
-// whose disparity exceeds x become 255 (cost <= 32, so OR-ing 0xFF works).
+// Hamming costs of a lane: wl[i] = censR[x - RP q - (RP-1) + i] (low half of register RP-1-i),
+// wh[j] = censR[x - (Dp-1) + RP q + j] (high half of register j).  With MASK the halves whose
+// disparity exceeds x become 255 (cost <= 32, so OR-ing 0xFF works): low half of register j when
+// j > tl = x - RP q, high half when j < th = Dp-1 - RP q - x.
 template <int RP, bool MASK>
-__device__ __forceinline__ void cost_from_census(const u32 (&wl)[RP], const u32 (&wh)[RP], u32 cl, int tl, u32 (&c)[RP])
+__device__ __forceinline__ void cost_from_census(const u32 (&wl)[RP], const u32 (&wh)[RP], u32 cl, int tl, int th, u32 (&c)[RP])
 {
-    constexpr int HALF = 16 * RP;
 #pragma unroll
     for (int j = 0; j < RP; j++) {
         const u32 lo = (u32)__builtin_popcount(wl[RP - 1 - j] ^ cl);
-        const u32 hi = (u32)__builtin_popcount(wh[RP - 1 - j] ^ cl);
+        const u32 hi = (u32)__builtin_popcount(wh[j] ^ cl);
         c[j] = lo | (hi << 16);
         if (MASK)
-            c[j] |= (j > tl ? 0xFFu : 0u) | (j > tl - HALF ? 0xFF0000u : 0u);
+            c[j] |= (j > tl ? 0xFFu : 0u) | (j < th ? 0xFF0000u : 0u);
     }
 }
 
@@ -166,12 +189,18 @@ __device__ __forceinline__ LaneGeom lane_geometry(int p, int w, int h, int dx, i
 // one scalar add.  For a negative stride the walk runs downwards from T|s| (T = longest path - 1)
 // and base' = base - T|s|, so soffset never goes negative; the descriptors are unbounded.
 // ---------------------------------------------------------------------------
-template <int RP, bool FIRST, bool HAS_PAD, int PF>
-__global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
+//
+// ACC: the E bytes of this direction are added onto the bytes already in the volume (the running sum
+// of a group of directions, G P2 <= 255) instead of starting a volume of their own.  The sweeps are
+// bound by VALU issue and leave HBM bandwidth unused; the read-modify-write moves traffic out of the
+// HBM-bound WTA kernel, which then reads N / G volumes.  Rows past the last path repeat the last path:
+// they read and write the same bytes in the same instructions of the same wave, so the sums stay right.
+template <int RP, bool FIRST, bool HAS_PAD, int PF, bool ACC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4 : 3))) void aggregate3_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
                                                          uint8_t *__restrict__ E, uint16_t *__restrict__ BL,
                                                          uint16_t *__restrict__ SB, const Agg2Args a)
 {
-    constexpr int Dp = 32 * RP, HALF = 16 * RP;
+    constexpr int Dp = 32 * RP, NW = (RP + 1) / 2;
     const int lane = threadIdx.x & 63;
     const int q = lane & 15;
     // XCD-aware block -> (pair, path group) map: workgroups are dealt round-robin over the 8 XCDs, so
@@ -215,7 +244,8 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
     const __amdgpu_buffer_rsrc_t rsE =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(E + (size_t)pair * npix * Dp) - soE0, 0, -1, 0x00020000);
     // lane parts: start pixel of the lane's path + its window / line slice
-    const unsigned voR = (unsigned)((g.y0 * wp + Dp + g.x0 - RP * q - (RP - 1) - HALF) * 4); // high-half window; low = + HALF*4
+    const unsigned voRl = (unsigned)((g.y0 * wp + Dp + g.x0 - RP * q - (RP - 1)) * 4); // low-half window
+    const unsigned voRh = (unsigned)((g.y0 * wp + g.x0 + 1 + RP * q) * 4);             // high-half window
     const unsigned voL = (unsigned)((g.y0 * w + g.x0) * 4);
     const unsigned voE = (unsigned)((g.y0 * w + g.x0) * Dp + 2 * RP * q);
     const size_t ring = (size_t)(2 * w + 2 * h) * (Dp / 2); // uint32 units
@@ -223,20 +253,21 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
     u32 *SBf = reinterpret_cast<u32 *>(SB) + (size_t)pair * ring + RP * q;
 
     const u32 P1p = (u32)a.P1 * 0x10001u, P2p = (u32)a.P2 * 0x10001u;
-    const int tl0 = g.x0 - RP * q; // x - RP q at step 0
+    const int tl0 = g.x0 - RP * q;          // x - RP q at step 0
+    const int th0 = Dp - 1 - RP * q - g.x0; // Dp-1 - RP q - x at step 0
     u32 padfloor[RP];
 #pragma unroll
     for (int j = 0; j < RP; j++)
-        padfloor[j] = (RP * q + j >= a.D ? INF16 : 0u) | (HALF + RP * q + j >= a.D ? INF16 << 16 : 0u);
+        padfloor[j] = (RP * q + j >= a.D ? INF16 : 0u) | (Dp - 1 - (RP * q + j) >= a.D ? INF16 << 16 : 0u);
 
     // ---- step 0, the start pixels: L_k = L_{k-1} + C; their E bytes are 0, the carry goes to SB
     u32 prior[RP];
     {
-        u32 wl[RP], wh[RP], c[RP], zero[RP];
-        buf_load_win<RP>(rsR, voR + HALF * 4, soR0, wl);
-        buf_load_win<RP>(rsR, voR, soR0, wh);
+        u32 wl[RP], wh[RP], c[RP];
+        buf_load_win<RP>(rsR, voRl, soR0, wl);
+        buf_load_win<RP>(rsR, voRh, soR0, wh);
         const u32 clv = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0, 0);
-        cost_from_census<RP, true>(wl, wh, clv, tl0, c);
+        cost_from_census<RP, true>(wl, wh, clv, tl0, th0, c);
         const size_t bo = (size_t)border_index(g.y0, g.x0, w, h) * (Dp / 2);
         if (FIRST) {
 #pragma unroll
@@ -258,9 +289,14 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
         for (int j = 0; j < RP; j++) {
             if (HAS_PAD)
                 prior[j] = pk_max(prior[j], padfloor[j]);
-            zero[j] = 0u;
         }
-        buf_store_e<RP>(rsE, voE, soE0, zero);
+        if (!ACC) {
+            u32 zero[NW];
+#pragma unroll
+            for (int m = 0; m < NW; m++)
+                zero[m] = 0u;
+            buf_store_ev<RP>(rsE, voE, soE0, zero);
+        }
         if (valid)
             __builtin_memcpy(BLf + bo, prior, 4 * RP);
     }
@@ -268,19 +304,21 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
         return;
 
     // ---- steps 1 .. len-1; ring slot i holds a step t with (t-1) % PF == i
-    u32 qwl[PF][RP], qwh[PF][RP], qcl[PF];
+    u32 qwl[PF][RP], qwh[PF][RP], qcl[PF], qe[ACC ? PF : 1][NW];
 #pragma unroll
     for (int i = 0; i < PF; i++)
         if (1 + i < len) {
-            buf_load_win<RP>(rsR, voR + HALF * 4, soR0 + (1 + i) * sR, qwl[i]);
-            buf_load_win<RP>(rsR, voR, soR0 + (1 + i) * sR, qwh[i]);
+            buf_load_win<RP>(rsR, voRl, soR0 + (1 + i) * sR, qwl[i]);
+            buf_load_win<RP>(rsR, voRh, soR0 + (1 + i) * sR, qwh[i]);
             qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0 + (1 + i) * sL, 0);
+            if (ACC)
+                buf_load_ev<RP>(rsE, voE, soE0 + (1 + i) * sE, qe[i]);
         }
     u32 *bl_last = BLf + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
-    const bool lane0 = q == 0, lane15 = q == 15;
+    u32 below = INF2; // "register -1": lanes 1..15 get it from lane q-1 every step, lane 0 keeps the INF pair
 
     unsigned soRp = soR0 + (1 + PF) * sR, soLp = soL0 + (1 + PF) * sL; // soffsets of the step PF ahead
-    unsigned soE = soE0;
+    unsigned soE = soE0, soEp = soE0 + (1 + PF) * sE;
     auto step = [&](auto maskc, auto slowc, int t, int i) {
         constexpr bool SLOW = decltype(slowc)::value;
         soE += sE;
@@ -291,22 +329,26 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
             wh[j] = qwh[i][j];
         }
         const u32 clv = qcl[i];
+        u32 ev[NW];
+        if (ACC) {
+#pragma unroll
+            for (int m = 0; m < NW; m++)
+                ev[m] = qe[i][m];
+        }
         if (!SLOW || t + PF < len) { // census words PF steps ahead (fast blocks: in range for every row)
-            buf_load_win<RP>(rsR, voR + HALF * 4, soRp, qwl[i]);
-            buf_load_win<RP>(rsR, voR, soRp, qwh[i]);
+            buf_load_win<RP>(rsR, voRl, soRp, qwl[i]);
+            buf_load_win<RP>(rsR, voRh, soRp, qwh[i]);
             qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
+            if (ACC)
+                buf_load_ev<RP>(rsE, voE, soEp, qe[i]);
         }
         soRp += sR;
         soLp += sL;
-        u32 c[RP];
-        cost_from_census<RP, decltype(maskc)::value>(wl, wh, clv, tl0 + t * a.dx, c);
-
-        // stereo_sgm.h:129-146.  d-1 of register 0: lane q-1's top register; in lane 0 the low half has
-        // no d-1 and the high half continues lane 15's low half.  d+1 of register RP-1 mirrors that.
-        const u32 rdn = row_ror<1>(prior[RP - 1]);
-        const u32 rup = row_ror<15>(prior[0]);
-        const u32 prev0 = lane0 ? ((rdn << 16) | INF16) : rdn;
-        const u32 nextT = lane15 ? __builtin_amdgcn_alignbit(INF16, rup, 16) : rup;
+        soEp += sE;
+        constexpr bool MASK = decltype(maskc)::value;
+        // stereo_sgm.h:129-146 in the mirrored layout (see the head of this file)
+        below = dpp<0x111>(below, prior[RP - 1]);                                                             // row_shr:1
+        const u32 above = dpp<0x101>(__builtin_amdgcn_alignbit(prior[RP - 1], prior[RP - 1], 16), prior[0]); // row_shl:1
         u32 mn = prior[0];
 #pragma unroll
         for (int j = 1; j < RP; j++)
@@ -315,21 +357,42 @@ __global__ __launch_bounds__(256) void aggregate3_kernel(const u32 *__restrict__
         u32 e[RP];
 #pragma unroll
         for (int j = 0; j < RP; j++) {
-            const u32 prev = j ? prior[j - 1] : prev0;
-            const u32 next = j < RP - 1 ? prior[j + 1] : nextT;
+            const u32 prev = j ? prior[j - 1] : below;
+            const u32 next = j < RP - 1 ? prior[j + 1] : above;
             const u32 A = pk_min(prior[j], pk_add(pk_min(prev, next), P1p));
             e[j] = pk_min(pk_sub(A, mp), P2p);
         }
+        if (MASK) {
+            u32 c[RP];
+            cost_from_census<RP, true>(wl, wh, clv, tl0 + t * a.dx, th0 - t * a.dx, c);
 #pragma unroll
-        for (int j = 0; j < RP; j++) {
-            prior[j] = pk_add(e[j], c[j]);
+            for (int j = 0; j < RP; j++)
+                prior[j] = pk_add(e[j], c[j]);
+        } else {
+            // L = E + C with the adds folded into the popcounts (v_bcnt accumulates) and the half merge
+#pragma unroll
+            for (int j = 0; j < RP; j++) {
+                u32 lo, hi;
+                asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(lo) : "v"(wl[RP - 1 - j] ^ clv), "v"(e[j])); // popcount + E pair
+                asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(hi) : "v"(wh[j] ^ clv));
+                asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(prior[j]) : "v"(hi), "v"(lo));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RP; j++)
             if (HAS_PAD)
                 prior[j] = pk_max(prior[j], padfloor[j]);
+        u32 eb[NW];
+        pack_e<RP>(e, eb);
+        if (ACC) {
+#pragma unroll
+            for (int m = 0; m < NW; m++)
+                eb[m] += ev[m]; // bytes: no carry while G P2 <= 255
         }
         if (!SLOW) {
-            buf_store_e<RP>(rsE, voE, soE, e);
+            buf_store_ev<RP>(rsE, voE, soE, eb);
         } else if (t < len) {
-            buf_store_e<RP>(rsE, voE, soE, e);
+            buf_store_ev<RP>(rsE, voE, soE, eb);
             if (valid) {
                 if (g.edge) // path along an image edge: every pixel feeds a later direction's start
                     __builtin_memcpy(BLf + (size_t)border_index(g.y0 + t * a.dy, g.x0 + t * a.dx, w, h) * (Dp / 2), prior, 4 * RP);
@@ -370,6 +433,7 @@ struct SumArgs {
     size_t estride; // bytes between the volumes of two directions
     const uint16_t *SB;
     int w, h, D, wp, N;
+    int NV; // byte volumes: each holds the summed E of N / NV consecutive directions
 };
 
 template <int RP> __device__ __forceinline__ void load_e_pairs(const uint8_t *p, u32 (&o)[RP]);
@@ -411,16 +475,16 @@ template <int RP> struct PixelRaw {
 template <int RP>
 __device__ __forceinline__ void load_pixel(const SumArgs &a, int pair, int y, int x, int q, PixelRaw<RP> &r)
 {
-    constexpr int Dp = 32 * RP, HALF = 16 * RP;
+    constexpr int Dp = 32 * RP;
     const size_t pix = ((size_t)pair * a.h + y) * a.w + x;
     r.clv = a.cl[pix];
-    const u32 *win = a.cr + ((size_t)pair * a.h + y) * a.wp + (Dp + x - RP * q - (RP - 1));
-    __builtin_memcpy(r.wl, win, 4 * RP);
-    __builtin_memcpy(r.wh, win - HALF, 4 * RP);
+    const u32 *row = a.cr + ((size_t)pair * a.h + y) * a.wp;
+    __builtin_memcpy(r.wl, row + (Dp + x - RP * q - (RP - 1)), 4 * RP);
+    __builtin_memcpy(r.wh, row + (x + 1 + RP * q), 4 * RP);
     const uint8_t *ep = a.E + pix * Dp + 2 * RP * q;
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        if (k < a.N) {
+        if (k < a.NV) {
             const uint8_t *pk = ep + (size_t)k * a.estride;
             // read once: non-temporal, like the stores that wrote them
             if constexpr (RP == 1) {
@@ -441,33 +505,23 @@ __device__ __forceinline__ void load_pixel(const SumArgs &a, int pair, int y, in
         }
 }
 
-// S = N C + sum_k E_k.  The E bytes of G volumes are added as packed bytes first (no carry while
-// G * P2 <= 255), then widened to the packed uint16 pairs.
-template <int RP, int G, bool MASK>
-__device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &r, int tl, u32 (&S)[RP])
+// S = N C + sum over the byte volumes (each already the sum of a group of directions, <= 255),
+// widened to the packed uint16 pairs.
+template <int RP, bool MASK>
+__device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &r, int x, int q, u32 (&S)[RP])
 {
-    constexpr int NW = (RP + 1) / 2;
     u32 c[RP];
-    cost_from_census<RP, MASK>(r.wl, r.wh, r.clv, tl, c);
+    cost_from_census<RP, MASK>(r.wl, r.wh, r.clv, x - RP * q, 32 * RP - 1 - RP * q - x, c);
     const int sh = a.N == 8 ? 3 : 2;
 #pragma unroll
     for (int j = 0; j < RP; j++)
         S[j] = c[j] << sh; // N * C
 #pragma unroll
-    for (int k0 = 0; k0 < 8; k0 += G)
-        if (k0 < a.N) {
-            u32 acc[NW];
-#pragma unroll
-            for (int m = 0; m < NW; m++)
-                acc[m] = r.ev[k0][m];
-#pragma unroll
-            for (int k = k0 + 1; k < k0 + G; k++)
-#pragma unroll
-                for (int m = 0; m < NW; m++)
-                    acc[m] += r.ev[k][m];
+    for (int k = 0; k < 8; k++)
+        if (k < a.NV) {
 #pragma unroll
             for (int j = 0; j < RP; j++)
-                S[j] = pk_add(S[j], __builtin_amdgcn_perm(0u, acc[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u));
+                S[j] = pk_add(S[j], __builtin_amdgcn_perm(0u, r.ev[k][j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u));
         }
 }
 
@@ -491,7 +545,7 @@ __device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, in
 {
     PixelRaw<RP> r;
     load_pixel<RP>(a, pair, y, x, q, r);
-    sum_pixel<RP, 1, true>(a, r, x - RP * q, S);
+    sum_pixel<RP, true>(a, r, x, q, S);
     add_border<RP>(a, pair, y, x, q, S);
 }
 
@@ -503,7 +557,7 @@ __device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, in
 // wins ties like its strict '<' scan.
 // ---------------------------------------------------------------------------
 template <int RP, bool HAS_PAD>
-__global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int m, uint16_t *__restrict__ raw)
+__global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint16_t *__restrict__ raw)
 {
     constexpr int Dp = 32 * RP, HALF = 16 * RP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -523,7 +577,6 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int 
     __syncthreads();
     u32 *mytile = tile + (wave * 4 + r) * (Dp / 2);
     const uint16_t *t16 = reinterpret_cast<const uint16_t *>(mytile);
-    const int G = P2 <= 31 ? 8 : (P2 <= 63 ? 4 : (P2 <= 127 ? 2 : 1)); // volumes whose bytes add without carry
     const bool border_row = y == 0 || y == h - 1;
 
     auto clampx = [&](int x0) { const int x = x0 + r; return x < w ? x : w - 1; };
@@ -540,51 +593,45 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int 
         const int xc = x < w ? x : w - 1;
         const int xb = xc - RP * q;                  // x - d_lo of register 0
         u32 S[RP];
-        if (full) {
-            if (G == 8)
-                sum_pixel<RP, 8, false>(a, cur, xb, S);
-            else if (G == 4)
-                sum_pixel<RP, 4, false>(a, cur, xb, S);
-            else if (G == 2)
-                sum_pixel<RP, 2, false>(a, cur, xb, S);
-            else
-                sum_pixel<RP, 1, false>(a, cur, xb, S);
-        } else {
-            sum_pixel<RP, 1, true>(a, cur, xb, S);
-        }
+        if (full)
+            sum_pixel<RP, false>(a, cur, xc, q, S);
+        else
+            sum_pixel<RP, true>(a, cur, xc, q, S);
         if (border_row || x0 == 0 || x0 + 3 >= w - 1)
             add_border<RP>(a, pair, y, xc, q, S);
         u32 best = 0xFFFFFFFFu;
-        u32 *rb = rkey + (xb - (RP - 1) - HALF); // slot of this lane's largest disparity; may lie below rkey when !full
+        // right-view slots x - d of this lane: low half of register j at rl[-j], high half at rh[j]
+        // (both may lie below rkey when !full; those are never touched)
+        u32 *rl = rkey + xb, *rh = rkey + (xc - (Dp - 1) + RP * q);
         if (full) {
 #pragma unroll
             for (int j = 0; j < RP; j++) {
-                const int dl = RP * q + j, dh = HALF + dl;
+                const int dl = RP * q + j, dh = Dp - 1 - dl;
                 const u32 kl = (S[j] << 16) | (u32)dl, kh = (S[j] & 0xFFFF0000u) | (u32)dh;
                 if (!HAS_PAD || dl < D) {
                     best = min(best, kl);
-                    atomicMin(rb + (RP - 1 - j) + HALF, kl);
+                    atomicMin(rl - j, kl);
                 }
                 if (!HAS_PAD || dh < D) {
                     best = min(best, kh);
-                    atomicMin(rb + (RP - 1 - j), kh);
+                    atomicMin(rh + j, kh);
                 }
             }
         } else {
             const bool active = x < w;
 #pragma unroll
             for (int j = 0; j < RP; j++) {
-                const int dl = RP * q + j, dh = HALF + dl;
+                const int dl = RP * q + j, dh = Dp - 1 - dl;
                 const u32 kl = (S[j] << 16) | (u32)dl, kh = (S[j] & 0xFFFF0000u) | (u32)dh;
                 if (active && dl < D) {
                     best = min(best, kl);
                     if (dl <= x)
-                        atomicMin(rb + (RP - 1 - j) + HALF, kl);
+                        atomicMin(rl - j, kl);
                 }
                 if (active && dh < D) {
                     best = min(best, kh);
                     if (dh <= x)
-                        atomicMin(rb + (RP - 1 - j), kh);
+                        atomicMin(rh + j, kh);
                 }
             }
         }
@@ -597,8 +644,8 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int 
             lkey[x] = best;
             const int d = (int)(best & 0xFFFFu);
             if (d >= 1 && d < D - 1) {
-                // element d of the tile: uint16 index 2 * (d mod HALF) + (d >= HALF)
-                auto at = [&](int dd) { return (u32)t16[2 * (dd >= HALF ? dd - HALF : dd) + (dd >= HALF ? 1 : 0)]; };
+                // element d of the tile: low half of word d, or high half of word Dp-1 - d
+                auto at = [&](int dd) { return (u32)t16[dd < HALF ? 2 * dd : 2 * (Dp - 1 - dd) + 1]; };
                 s3a[x] = at(d - 1) | (at(d) << 16);
                 s3b[x] = at(d + 1);
             }
@@ -633,7 +680,7 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int 
 template <int RP>
 __global__ __launch_bounds__(256) void sums_tap_kernel(const SumArgs a, int pair, uint16_t *__restrict__ out)
 {
-    constexpr int HALF = 16 * RP;
+    constexpr int Dp = 32 * RP;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t pixi = t / 16;
     const int q = (int)(t % 16);
@@ -644,7 +691,7 @@ __global__ __launch_bounds__(256) void sums_tap_kernel(const SumArgs a, int pair
     pixel_sums<RP>(a, pair, y, x, q, S);
 #pragma unroll
     for (int j = 0; j < RP; j++) {
-        const int dl = RP * q + j, dh = HALF + dl;
+        const int dl = RP * q + j, dh = Dp - 1 - dl;
         if (dl < a.D)
             out[pixi * a.D + dl] = (uint16_t)(S[j] & 0xFFFFu);
         if (dh < a.D)
