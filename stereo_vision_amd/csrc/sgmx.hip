@@ -63,8 +63,7 @@ struct sgmx_ctx {
     void *d_C = nullptr;   // uint8 or float, pitch Dp
     void *d_S = nullptr;   // uint16 or float, pitch Dp
     void *d_BL = nullptr;  // border ring
-    uint8_t *d_E = nullptr;     // fast path: ceil(num_paths / egroup) byte volumes, [g][max_batch][h][w][Dp]
-    int egroup = 1;             // directions summed into one byte volume (egroup * P2 <= 255)
+    uint8_t *d_E = nullptr;     // fast path: num_paths byte volumes, [k][max_batch][h][w][Dp]
     uint16_t *d_SB = nullptr;   // fast path: border accumulator, same shape as d_BL
     size_t bytes_E = 0;         // one pair of one direction
     uint16_t *d_raw = nullptr, *d_out = nullptr;
@@ -161,8 +160,7 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
     HIPCHK(c, hipMalloc(&c->d_BL, c->bytes_BL * B));
     if (fast) {
         c->bytes_E = npix * c->DpF;
-        const int nvol = (c->prm.num_paths + c->egroup - 1) / c->egroup;
-        HIPCHK(c, hipMalloc((void **)&c->d_E, c->bytes_E * B * nvol));
+        HIPCHK(c, hipMalloc((void **)&c->d_E, c->bytes_E * B * c->prm.num_paths));
         HIPCHK(c, hipMalloc((void **)&c->d_SB, c->bytes_BL * B));
         // small launch groups are latency-bound and run faster on the one-path-per-wave kernels
         const int ns = c->small_n < B ? c->small_n : B;
@@ -327,32 +325,21 @@ int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t s
     return SGMX_OK;
 }
 
-template <int RP, int PF, bool ACC>
-void launch_agg3_pf(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr, uint8_t *E, uint16_t *BL,
-                    uint16_t *SB, const Agg2Args &a)
-{
-    if (first) {
-        if (pad)
-            hipLaunchKernelGGL((aggregate3_kernel<RP, true, true, PF, ACC>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
-        else
-            hipLaunchKernelGGL((aggregate3_kernel<RP, true, false, PF, ACC>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
-    } else {
-        if (pad)
-            hipLaunchKernelGGL((aggregate3_kernel<RP, false, true, PF, ACC>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
-        else
-            hipLaunchKernelGGL((aggregate3_kernel<RP, false, false, PF, ACC>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
-    }
-}
-
-// acc: add this direction's E bytes onto the volume (a later direction of a group) instead of starting it
-template <int RP> void launch_agg3(bool first, bool acc, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
+template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
                                    uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a)
 {
     constexpr int PF = RP == 8 ? 2 : 4; // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
-    if (acc)
-        launch_agg3_pf<RP, PF, true>(false, pad, grid, st, cl, cr, E, BL, SB, a);
-    else
-        launch_agg3_pf<RP, PF, false>(first, pad, grid, st, cl, cr, E, BL, SB, a);
+    if (first) {
+        if (pad)
+            hipLaunchKernelGGL((aggregate3_kernel<RP, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+        else
+            hipLaunchKernelGGL((aggregate3_kernel<RP, true, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+    } else {
+        if (pad)
+            hipLaunchKernelGGL((aggregate3_kernel<RP, false, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+        else
+            hipLaunchKernelGGL((aggregate3_kernel<RP, false, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
+    }
 }
 
 SumArgs sum_args(const sgmx_ctx *c)
@@ -368,7 +355,6 @@ SumArgs sum_args(const sgmx_ctx *c)
     a.D = c->prm.disp_range;
     a.wp = c->wp;
     a.N = c->prm.num_paths;
-    a.NV = (c->prm.num_paths + c->egroup - 1) / c->egroup;
     return a;
 }
 
@@ -395,18 +381,16 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
         a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
         a.npairs = n;
         const dim3 grid(8 * ((a.npaths + 15) / 16) * ((n + 7) / 8)); // 4 waves x 4 paths per workgroup, XCD-major pairs
-        // directions k of one group (egroup * P2 <= 255) share a volume: the first writes, the others add
-        uint8_t *Ek = c->d_E + (size_t)(k / c->egroup) * c->bytes_E * c->prm.max_batch;
-        const bool acc = k % c->egroup != 0;
+        uint8_t *Ek = c->d_E + (size_t)k * c->bytes_E * c->prm.max_batch;
         ProfScope ps(c, SGMX_K_AGGREGATE, st);
         if (c->RP == 1)
-            launch_agg3<1>(k == 0, acc, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<1>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
         else if (c->RP == 2)
-            launch_agg3<2>(k == 0, acc, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<2>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
         else if (c->RP == 4)
-            launch_agg3<4>(k == 0, acc, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<4>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
         else
-            launch_agg3<8>(k == 0, acc, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<8>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
         HIPCHK(c, hipGetLastError());
     }
     {
@@ -415,18 +399,19 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
         const size_t lds = wta3_lds_bytes(c);
         const dim3 grid(c->h, n);
         const bool wpad = c->prm.disp_range != c->DpF;
+        const int P2 = c->prm.penalty2;
 #define SGMX_WTA(RPV)                                                                                                  \
     do {                                                                                                               \
         if (wpad) {                                                                                                    \
             if (lds > 64 * 1024)                                                                                       \
                 HIPCHK(c, hipFuncSetAttribute((const void *)wta3_kernel<RPV, true>,                                    \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            hipLaunchKernelGGL((wta3_kernel<RPV, true>), grid, dim3(256), lds, st, sa, c->m, c->d_raw);             \
+            hipLaunchKernelGGL((wta3_kernel<RPV, true>), grid, dim3(256), lds, st, sa, P2, c->m, c->d_raw);             \
         } else {                                                                                                       \
             if (lds > 64 * 1024)                                                                                       \
                 HIPCHK(c, hipFuncSetAttribute((const void *)wta3_kernel<RPV, false>,                                   \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            hipLaunchKernelGGL((wta3_kernel<RPV, false>), grid, dim3(256), lds, st, sa, c->m, c->d_raw);            \
+            hipLaunchKernelGGL((wta3_kernel<RPV, false>), grid, dim3(256), lds, st, sa, P2, c->m, c->d_raw);            \
         }                                                                                                              \
     } while (0)
         if (c->RP == 1)
@@ -657,15 +642,6 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->small_n = (p.flags & SGMX_FLAG_NO_SMALL_GROUPS) ? 0 : 3; // measured crossover at KITTI size: between 3 and 4 pairs
     c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : 8));
     c->DpF = 32 * c->RP;
-    {
-        const int P2 = p.penalty2 > 0 ? p.penalty2 : 1;
-        int cap = 255 / P2; // E <= P2: this many directions add up inside a byte
-        cap = cap >= 8 ? 8 : (cap >= 4 ? 4 : (cap >= 2 ? 2 : 1));
-        int g = 1; // measured: a volume per direction is faster (the read-modify-write sweeps lose more than the WTA gains)
-        if (const char *e = getenv("SGMX_EGROUP")) // experiment switch
-            g = atoi(e) > cap ? cap : (atoi(e) > 0 ? atoi(e) : 1);
-        c->egroup = g < p.num_paths ? g : p.num_paths;
-    }
     bool ok = hipSetDevice(p.device) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess &&
               hipStreamCreate(&c->copy_stream) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++)

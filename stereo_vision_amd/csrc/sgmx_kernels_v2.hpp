@@ -124,23 +124,6 @@ __device__ __forceinline__ void buf_store_ev(__amdgpu_buffer_rsrc_t rs, unsigned
         __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, E_STORE_AUX);
     }
 }
-// the same bytes back (accumulating sweeps), non-temporal like the stores
-template <int RP>
-__device__ __forceinline__ void buf_load_ev(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&v)[(RP + 1) / 2])
-{
-    if constexpr (RP == 1) {
-        v[0] = (u32)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, E_STORE_AUX);
-    } else if constexpr (RP == 2) {
-        v[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, E_STORE_AUX);
-    } else if constexpr (RP == 4) {
-        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, E_STORE_AUX);
-        v[0] = t.x; v[1] = t.y;
-    } else {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, E_STORE_AUX);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
-}
-
 // Hamming costs of a lane: wl[i] = censR[x - RP q - (RP-1) + i] (low half of register RP-1-i),
 // wh[j] = censR[x - (Dp-1) + RP q + j] (high half of register j).  With MASK the halves whose
 // disparity exceeds x become 255 (cost <= 32, so OR-ing 0xFF works): low half of register j when
@@ -189,13 +172,7 @@ __device__ __forceinline__ LaneGeom lane_geometry(int p, int w, int h, int dx, i
 // one scalar add.  For a negative stride the walk runs downwards from T|s| (T = longest path - 1)
 // and base' = base - T|s|, so soffset never goes negative; the descriptors are unbounded.
 // ---------------------------------------------------------------------------
-//
-// ACC: the E bytes of this direction are added onto the bytes already in the volume (the running sum
-// of a group of directions, G P2 <= 255) instead of starting a volume of their own.  The sweeps are
-// bound by VALU issue and leave HBM bandwidth unused; the read-modify-write moves traffic out of the
-// HBM-bound WTA kernel, which then reads N / G volumes.  Rows past the last path repeat the last path:
-// they read and write the same bytes in the same instructions of the same wave, so the sums stay right.
-template <int RP, bool FIRST, bool HAS_PAD, int PF, bool ACC>
+template <int RP, bool FIRST, bool HAS_PAD, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4 : 3))) void aggregate3_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
                                                          uint8_t *__restrict__ E, uint16_t *__restrict__ BL,
                                                          uint16_t *__restrict__ SB, const Agg2Args a)
@@ -249,6 +226,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     const unsigned voL = (unsigned)((g.y0 * w + g.x0) * 4);
     const unsigned voE = (unsigned)((g.y0 * w + g.x0) * Dp + 2 * RP * q);
     const size_t ring = (size_t)(2 * w + 2 * h) * (Dp / 2); // uint32 units
+    // Paths along an image edge write L of every pixel into the ring.  Away from the corners (steps
+    // 1 .. len-2) the ring slot is linear in the step, so the steady-state loop stores through a
+    // descriptor with a walking soffset like the other streams.
+    const int sBi = (a.dy == 0 ? a.dx : a.dy) * Dp * 2;
+    const unsigned soB0 = sBi < 0 ? T * (unsigned)(-sBi) : 0u, sB = (unsigned)sBi;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(reinterpret_cast<u32 *>(BL) + (size_t)pair * ring) - soB0, 0, -1, 0x00020000);
+    const int bi0 = a.dy == 0 ? (g.y0 == 0 ? 0 : w) + g.x0 : 2 * w + (g.x0 == 0 ? 0 : h) + g.y0;
+    const unsigned voB = (unsigned)((bi0 * (Dp / 2) + RP * q) * 4);
+    const bool edge_store = g.edge && valid;
     u32 *BLf = reinterpret_cast<u32 *>(BL) + (size_t)pair * ring + RP * q;
     u32 *SBf = reinterpret_cast<u32 *>(SB) + (size_t)pair * ring + RP * q;
 
@@ -290,13 +277,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             if (HAS_PAD)
                 prior[j] = pk_max(prior[j], padfloor[j]);
         }
-        if (!ACC) {
-            u32 zero[NW];
+        u32 zero[NW];
 #pragma unroll
-            for (int m = 0; m < NW; m++)
-                zero[m] = 0u;
-            buf_store_ev<RP>(rsE, voE, soE0, zero);
-        }
+        for (int m = 0; m < NW; m++)
+            zero[m] = 0u;
+        buf_store_ev<RP>(rsE, voE, soE0, zero);
         if (valid)
             __builtin_memcpy(BLf + bo, prior, 4 * RP);
     }
@@ -304,24 +289,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         return;
 
     // ---- steps 1 .. len-1; ring slot i holds a step t with (t-1) % PF == i
-    u32 qwl[PF][RP], qwh[PF][RP], qcl[PF], qe[ACC ? PF : 1][NW];
+    u32 qwl[PF][RP], qwh[PF][RP], qcl[PF];
 #pragma unroll
     for (int i = 0; i < PF; i++)
         if (1 + i < len) {
             buf_load_win<RP>(rsR, voRl, soR0 + (1 + i) * sR, qwl[i]);
             buf_load_win<RP>(rsR, voRh, soR0 + (1 + i) * sR, qwh[i]);
             qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0 + (1 + i) * sL, 0);
-            if (ACC)
-                buf_load_ev<RP>(rsE, voE, soE0 + (1 + i) * sE, qe[i]);
         }
     u32 *bl_last = BLf + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
     u32 below = INF2; // "register -1": lanes 1..15 get it from lane q-1 every step, lane 0 keeps the INF pair
 
     unsigned soRp = soR0 + (1 + PF) * sR, soLp = soL0 + (1 + PF) * sL; // soffsets of the step PF ahead
-    unsigned soE = soE0, soEp = soE0 + (1 + PF) * sE;
-    auto step = [&](auto maskc, auto slowc, int t, int i) {
-        constexpr bool SLOW = decltype(slowc)::value;
+    unsigned soE = soE0, soB = soB0;
+    auto step = [&](auto maskc, auto slowc, auto edgec, int t, int i) {
+        constexpr bool SLOW = decltype(slowc)::value, EDGE = decltype(edgec)::value;
         soE += sE;
+        soB += sB;
         u32 wl[RP], wh[RP];
 #pragma unroll
         for (int j = 0; j < RP; j++) {
@@ -329,22 +313,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             wh[j] = qwh[i][j];
         }
         const u32 clv = qcl[i];
-        u32 ev[NW];
-        if (ACC) {
-#pragma unroll
-            for (int m = 0; m < NW; m++)
-                ev[m] = qe[i][m];
-        }
         if (!SLOW || t + PF < len) { // census words PF steps ahead (fast blocks: in range for every row)
             buf_load_win<RP>(rsR, voRl, soRp, qwl[i]);
             buf_load_win<RP>(rsR, voRh, soRp, qwh[i]);
             qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
-            if (ACC)
-                buf_load_ev<RP>(rsE, voE, soEp, qe[i]);
         }
         soRp += sR;
         soLp += sL;
-        soEp += sE;
         constexpr bool MASK = decltype(maskc)::value;
         // stereo_sgm.h:129-146 in the mirrored layout (see the head of this file)
         below = dpp<0x111>(below, prior[RP - 1]);                                                             // row_shr:1
@@ -384,13 +359,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
                 prior[j] = pk_max(prior[j], padfloor[j]);
         u32 eb[NW];
         pack_e<RP>(e, eb);
-        if (ACC) {
-#pragma unroll
-            for (int m = 0; m < NW; m++)
-                eb[m] += ev[m]; // bytes: no carry while G P2 <= 255
-        }
         if (!SLOW) {
             buf_store_ev<RP>(rsE, voE, soE, eb);
+            if (EDGE && edge_store) {
+                if constexpr (RP == 1) {
+                    __builtin_amdgcn_raw_buffer_store_b32(prior[0], rsB, voB, soB, 0);
+                } else if constexpr (RP == 2) {
+                    u32x2 v;
+                    v.x = prior[0]; v.y = prior[1];
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rsB, voB, soB, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < RP / 4; m++) {
+                        u32x4 v;
+                        v.x = prior[4 * m]; v.y = prior[4 * m + 1]; v.z = prior[4 * m + 2]; v.w = prior[4 * m + 3];
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsB, voB + 16 * m, soB, 0);
+                    }
+                }
+            }
         } else if (t < len) {
             buf_store_ev<RP>(rsE, voE, soE, eb);
             if (valid) {
@@ -402,23 +388,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         }
     };
 
-    for (int t = 1; t < maxlen; t += PF) {
-        if (!any_edge && t + 2 * PF <= minlen) { // every row: steps t..t+PF-1 and their prefetch targets exist, none is last
-            const int xa = minx + t * a.dx, xb = minx + (t + PF - 1) * a.dx;
-            if ((xa < xb ? xa : xb) < a.D - 1) { // some d > x in this block: costs need the 255 mask
+    // every d <= x for all four rows in steps t .. t+PF-1 (otherwise the costs need the 255 mask)
+    auto unmasked = [&](int t) {
+        const int xa = minx + t * a.dx, xb = minx + (t + PF - 1) * a.dx;
+        return (xa < xb ? xa : xb) >= a.D - 1;
+    };
+    int t = 1;
+    while (t < maxlen) {
+        if (t + 2 * PF <= minlen) { // every row: steps t..t+PF-1 and their prefetch targets exist, none is last
+            if (unmasked(t)) {
+                // The steady state is a loop of its own: sharing one loop with the masked and the last-steps
+                // variants made the compiler copy the whole prefetch ring and drain vmcnt every block.
+                if (any_edge) {
+                    do {
 #pragma unroll
-                for (int i = 0; i < PF; i++)
-                    step(BoolC<true>(), BoolC<false>(), t + i, i);
+                        for (int i = 0; i < PF; i++)
+                            step(BoolC<false>(), BoolC<false>(), BoolC<true>(), t + i, i);
+                        t += PF;
+                    } while (t + 2 * PF <= minlen && unmasked(t));
+                } else {
+                    do {
+#pragma unroll
+                        for (int i = 0; i < PF; i++)
+                            step(BoolC<false>(), BoolC<false>(), BoolC<false>(), t + i, i);
+                        t += PF;
+                    } while (t + 2 * PF <= minlen && unmasked(t));
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < PF; i++)
-                    step(BoolC<false>(), BoolC<false>(), t + i, i);
+                    step(BoolC<true>(), BoolC<false>(), BoolC<true>(), t + i, i);
+                t += PF;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < PF; i++)
                 if (t + i < maxlen)
-                    step(BoolC<true>(), BoolC<true>(), t + i, i);
+                    step(BoolC<true>(), BoolC<true>(), BoolC<true>(), t + i, i);
+            t += PF;
         }
     }
 }
@@ -433,7 +440,6 @@ struct SumArgs {
     size_t estride; // bytes between the volumes of two directions
     const uint16_t *SB;
     int w, h, D, wp, N;
-    int NV; // byte volumes: each holds the summed E of N / NV consecutive directions
 };
 
 template <int RP> __device__ __forceinline__ void load_e_pairs(const uint8_t *p, u32 (&o)[RP]);
@@ -484,7 +490,7 @@ __device__ __forceinline__ void load_pixel(const SumArgs &a, int pair, int y, in
     const uint8_t *ep = a.E + pix * Dp + 2 * RP * q;
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        if (k < a.NV) {
+        if (k < a.N) {
             const uint8_t *pk = ep + (size_t)k * a.estride;
             // read once: non-temporal, like the stores that wrote them
             if constexpr (RP == 1) {
@@ -505,11 +511,12 @@ __device__ __forceinline__ void load_pixel(const SumArgs &a, int pair, int y, in
         }
 }
 
-// S = N C + sum over the byte volumes (each already the sum of a group of directions, <= 255),
-// widened to the packed uint16 pairs.
-template <int RP, bool MASK>
+// S = N C + sum_k E_k.  The E bytes of G volumes are added as packed bytes first (no carry while
+// G * P2 <= 255), then widened to the packed uint16 pairs.
+template <int RP, int G, bool MASK>
 __device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &r, int x, int q, u32 (&S)[RP])
 {
+    constexpr int NW = (RP + 1) / 2;
     u32 c[RP];
     cost_from_census<RP, MASK>(r.wl, r.wh, r.clv, x - RP * q, 32 * RP - 1 - RP * q - x, c);
     const int sh = a.N == 8 ? 3 : 2;
@@ -517,11 +524,20 @@ __device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &
     for (int j = 0; j < RP; j++)
         S[j] = c[j] << sh; // N * C
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (k < a.NV) {
+    for (int k0 = 0; k0 < 8; k0 += G)
+        if (k0 < a.N) {
+            u32 acc[NW];
+#pragma unroll
+            for (int m = 0; m < NW; m++)
+                acc[m] = r.ev[k0][m];
+#pragma unroll
+            for (int k = k0 + 1; k < k0 + G; k++)
+#pragma unroll
+                for (int m = 0; m < NW; m++)
+                    acc[m] += r.ev[k][m];
 #pragma unroll
             for (int j = 0; j < RP; j++)
-                S[j] = pk_add(S[j], __builtin_amdgcn_perm(0u, r.ev[k][j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u));
+                S[j] = pk_add(S[j], __builtin_amdgcn_perm(0u, acc[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u));
         }
 }
 
@@ -545,7 +561,7 @@ __device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, in
 {
     PixelRaw<RP> r;
     load_pixel<RP>(a, pair, y, x, q, r);
-    sum_pixel<RP, true>(a, r, x, q, S);
+    sum_pixel<RP, 1, true>(a, r, x, q, S);
     add_border<RP>(a, pair, y, x, q, S);
 }
 
@@ -557,7 +573,7 @@ __device__ __forceinline__ void pixel_sums(const SumArgs &a, int pair, int y, in
 // wins ties like its strict '<' scan.
 // ---------------------------------------------------------------------------
 template <int RP, bool HAS_PAD>
-__global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint16_t *__restrict__ raw)
+__global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int m, uint16_t *__restrict__ raw)
 {
     constexpr int Dp = 32 * RP, HALF = 16 * RP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -577,6 +593,7 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint1
     __syncthreads();
     u32 *mytile = tile + (wave * 4 + r) * (Dp / 2);
     const uint16_t *t16 = reinterpret_cast<const uint16_t *>(mytile);
+    const int G = P2 <= 31 ? 8 : (P2 <= 63 ? 4 : (P2 <= 127 ? 2 : 1)); // volumes whose bytes add without carry
     const bool border_row = y == 0 || y == h - 1;
 
     auto clampx = [&](int x0) { const int x = x0 + r; return x < w ? x : w - 1; };
@@ -593,10 +610,18 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int m, uint1
         const int xc = x < w ? x : w - 1;
         const int xb = xc - RP * q;                  // x - d_lo of register 0
         u32 S[RP];
-        if (full)
-            sum_pixel<RP, false>(a, cur, xc, q, S);
-        else
-            sum_pixel<RP, true>(a, cur, xc, q, S);
+        if (full) {
+            if (G == 8)
+                sum_pixel<RP, 8, false>(a, cur, xc, q, S);
+            else if (G == 4)
+                sum_pixel<RP, 4, false>(a, cur, xc, q, S);
+            else if (G == 2)
+                sum_pixel<RP, 2, false>(a, cur, xc, q, S);
+            else
+                sum_pixel<RP, 1, false>(a, cur, xc, q, S);
+        } else {
+            sum_pixel<RP, 1, true>(a, cur, xc, q, S);
+        }
         if (border_row || x0 == 0 || x0 + 3 >= w - 1)
             add_border<RP>(a, pair, y, xc, q, S);
         u32 best = 0xFFFFFFFFu;
