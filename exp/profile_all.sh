@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage (on the GPU box): exp/profile_all.sh TAG
+# rocprofv3 kernel stats of the default bench, then FETCH_SIZE and WRITE_SIZE in PMC passes of their own;
+# summaries land in gpurun_out/prof_TAG/ (copy what is judged into profiles/).
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/prof_$tag
+mkdir -p $out
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 2 --cpu-frames 0 > $out/bench_under_rocprof.json 2> $out/stats.log || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-events > $out/fetch.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-events > $out/write.log 2>&1 || exit 1
+python3 exp/mkprofiles.py $tag

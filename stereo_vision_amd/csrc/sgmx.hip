@@ -328,7 +328,10 @@ int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t s
 template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
                                    uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a)
 {
-    constexpr int PF = RP == 8 ? 2 : 4; // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
+#ifndef SGMX_PF
+#define SGMX_PF 4
+#endif
+    constexpr int PF = RP == 8 ? 2 : SGMX_PF; // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
     if (first) {
         if (pad)
             hipLaunchKernelGGL((aggregate3_kernel<RP, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);

@@ -313,13 +313,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             wh[j] = qwh[i][j];
         }
         const u32 clv = qcl[i];
-        if (!SLOW || t + PF < len) { // census words PF steps ahead (fast blocks: in range for every row)
-            buf_load_win<RP>(rsR, voRl, soRp, qwl[i]);
-            buf_load_win<RP>(rsR, voRh, soRp, qwh[i]);
-            qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
-        }
-        soRp += sR;
-        soLp += sL;
+        auto prefetch = [&]() { // census words PF steps ahead, into the ring slot this step has just consumed
+            if (!SLOW || t + PF < len) { // (fast blocks: in range for every row)
+                buf_load_win<RP>(rsR, voRl, soRp, qwl[i]);
+                buf_load_win<RP>(rsR, voRh, soRp, qwh[i]);
+                qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
+            }
+            soRp += sR;
+            soLp += sL;
+        };
+        if (SLOW)
+            prefetch();
         constexpr bool MASK = decltype(maskc)::value;
         // stereo_sgm.h:129-146 in the mirrored layout (see the head of this file)
         below = dpp<0x111>(below, prior[RP - 1]);                                                             // row_shr:1
@@ -357,6 +361,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         for (int j = 0; j < RP; j++)
             if (HAS_PAD)
                 prior[j] = pk_max(prior[j], padfloor[j]);
+        if (!SLOW) {
+            // after the slot's last use, and not hoisted above it: otherwise the compiler copies the slot
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch();
+        }
         u32 eb[NW];
         pack_e<RP>(e, eb);
         if (!SLOW) {
@@ -393,33 +402,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         const int xa = minx + t * a.dx, xb = minx + (t + PF - 1) * a.dx;
         return (xa < xb ? xa : xb) >= a.D - 1;
     };
+    // A run of full blocks of one kind is a loop of its own: sharing one loop between the kinds made the
+    // compiler copy the whole prefetch ring and drain vmcnt in every block.
     int t = 1;
+    auto run = [&](auto maskc, auto edgec) {
+        do {
+#pragma unroll
+            for (int i = 0; i < PF; i++)
+                step(maskc, BoolC<false>(), edgec, t + i, i);
+            t += PF;
+        } while (t + 2 * PF <= minlen && unmasked(t) != decltype(maskc)::value);
+    };
     while (t < maxlen) {
         if (t + 2 * PF <= minlen) { // every row: steps t..t+PF-1 and their prefetch targets exist, none is last
-            if (unmasked(t)) {
-                // The steady state is a loop of its own: sharing one loop with the masked and the last-steps
-                // variants made the compiler copy the whole prefetch ring and drain vmcnt every block.
-                if (any_edge) {
-                    do {
-#pragma unroll
-                        for (int i = 0; i < PF; i++)
-                            step(BoolC<false>(), BoolC<false>(), BoolC<true>(), t + i, i);
-                        t += PF;
-                    } while (t + 2 * PF <= minlen && unmasked(t));
-                } else {
-                    do {
-#pragma unroll
-                        for (int i = 0; i < PF; i++)
-                            step(BoolC<false>(), BoolC<false>(), BoolC<false>(), t + i, i);
-                        t += PF;
-                    } while (t + 2 * PF <= minlen && unmasked(t));
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < PF; i++)
-                    step(BoolC<true>(), BoolC<false>(), BoolC<true>(), t + i, i);
-                t += PF;
-            }
+            if (!unmasked(t))
+                run(BoolC<true>(), BoolC<true>());
+            else if (any_edge)
+                run(BoolC<false>(), BoolC<true>());
+            else
+                run(BoolC<false>(), BoolC<false>());
         } else {
 #pragma unroll
             for (int i = 0; i < PF; i++)
