@@ -65,8 +65,8 @@ typedef struct sgmx_params {
  * census path recomputes C from the census images and stores one byte per voxel and direction
  * instead; the results are identical.  penalty2 > 255 always uses the materialised form. */
 #define SGMX_FLAG_MATERIALIZE 1
-/* flags: by default launch groups of at most 3 pairs (e.g. every single-pair call) run on the
- * materialised kernels even when the volume-free formulation is eligible, because they are
+/* flags: by default a launch group of one pair (every single-pair call) runs on the
+ * materialised kernels even when the volume-free formulation is eligible, because it is
  * latency-bound and those kernels have the shorter step; this flag disables that switch. */
 #define SGMX_FLAG_NO_SMALL_GROUPS 2
 
