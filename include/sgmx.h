@@ -183,6 +183,25 @@ SGMX_API int sgmx_hamming_volume_u8(sgmx_ctx *ctx, const uint32_t *census_left, 
 SGMX_API int sgmx_hamming_matrix_u16(sgmx_ctx *ctx, uint16_t *dis, const uint8_t *a, const uint8_t *b, int na, int nb,
                                      int ncodes);
 
+/* Thresholded matching of binary signatures, the rest of the core/hamming library
+ * (core/hamming.h:73-104).  Signatures are ncodes bytes each; a match is a pair whose Hamming
+ * distance is <= ht.  Matches come in the reference's loop order (query i outer, base j inner):
+ *   idx[2p] = i, idx[2p+1] = j, hams[p] = distance      (core/hamming.c:743-762, 817-837)
+ * The reference's prealloc forms trust the caller's buffers; here `capacity` (in matches) is
+ * checked: when it is too small nothing is written, *nptr holds the count needed and the call
+ * returns SGMX_ERR_INVALID_ARG.  Typical use, as in the reference: count, allocate, prealloc.
+ *   sgmx_match_hamming_count           match_hamming_count           core/hamming.h:75-76
+ *   sgmx_crossmatch_hamming_count      crossmatch_hamming_count      core/hamming.h:78-79  (pairs j > i of one set)
+ *   sgmx_match_hamming_thres_prealloc  match_hamming_thres_prealloc  core/hamming.h:90-92
+ *   sgmx_crossmatch_hamming_prealloc   crossmatch_hamming_prealloc   core/hamming.h:103-104 */
+SGMX_API int sgmx_match_hamming_count(sgmx_ctx *ctx, const uint8_t *bs1, const uint8_t *bs2, int n1, int n2, int ht, int ncodes,
+                                      size_t *nptr);
+SGMX_API int sgmx_crossmatch_hamming_count(sgmx_ctx *ctx, const uint8_t *dbs, long n, int ht, int ncodes, size_t *nptr);
+SGMX_API int sgmx_match_hamming_thres_prealloc(sgmx_ctx *ctx, const uint8_t *bs1, const uint8_t *bs2, int n1, int n2, int ht,
+                                               int ncodes, int *idx, uint16_t *hams, size_t capacity, size_t *nptr);
+SGMX_API int sgmx_crossmatch_hamming_prealloc(sgmx_ctx *ctx, const uint8_t *dbs, long n, int ht, int ncodes, int *idx,
+                                              uint16_t *hams, size_t capacity, size_t *nptr);
+
 /* After a compute call, copy stages of pair `index` (0-based within the last
  * launch group) to the host: the data cost C [h][w][D] (uint8 for the census
  * path -- costs at stereo_sgm.cc:31-51; float for the float path), the summed

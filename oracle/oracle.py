@@ -129,6 +129,52 @@ def ref_hamming_matrix(a, b):
     return out
 
 
+def match_hamming(bs1, bs2, ht, cross=False):
+    """Restatement of match_hamming_thres_prealloc / crossmatch_hamming_prealloc: idx (n, 2), hams (n,)."""
+    a = np.ascontiguousarray(bs1, np.uint8)
+    b = a if cross else np.ascontiguousarray(bs2, np.uint8)
+    L = lib()
+    L.oracle_match_hamming.argtypes = [u8p, u8p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.oracle_match_hamming.restype = C.c_size_t
+    n = L.oracle_match_hamming(a, b, a.shape[0], b.shape[0], ht, a.shape[1], int(cross), None, None)
+    idx = np.empty((n, 2), np.int32)
+    hams = np.empty((n,), np.uint16)
+    n2 = L.oracle_match_hamming(a, b, a.shape[0], b.shape[0], ht, a.shape[1], int(cross), idx.ctypes.data, hams.ctypes.data)
+    assert n2 == n
+    return idx, hams
+
+
+def ref_match_hamming(bs1, bs2, ht, cross=False):
+    """The reference's own core/hamming.c (oracle/_ref): match_hamming_count + match_hamming_thres_prealloc,
+    or crossmatch_hamming_count + crossmatch_hamming_prealloc.  None when that build is absent."""
+    if not os.path.exists(_REF_HAMMING):
+        return None
+    L = C.CDLL(_REF_HAMMING)
+    a = np.ascontiguousarray(bs1, np.uint8)
+    n = C.c_size_t(0)
+    if cross:
+        L.crossmatch_hamming_count.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.crossmatch_hamming_count.restype = None
+        L.crossmatch_hamming_count(a, a.shape[0], ht, a.shape[1], C.byref(n))
+    else:
+        b = np.ascontiguousarray(bs2, np.uint8)
+        L.match_hamming_count.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.match_hamming_count.restype = None
+        L.match_hamming_count(a, b, a.shape[0], b.shape[0], ht, a.shape[1], C.byref(n))
+    idx = np.empty((n.value, 2), np.int32)
+    hams = np.empty((n.value,), np.uint16)
+    if cross:
+        L.crossmatch_hamming_prealloc.argtypes = [u8p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.crossmatch_hamming_prealloc.restype = C.c_size_t
+        got = L.crossmatch_hamming_prealloc(a, a.shape[0], ht, a.shape[1], idx.ctypes.data, hams.ctypes.data)
+    else:
+        L.match_hamming_thres_prealloc.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.match_hamming_thres_prealloc.restype = C.c_size_t
+        got = L.match_hamming_thres_prealloc(a, b, a.shape[0], b.shape[0], ht, a.shape[1], idx.ctypes.data, hams.ctypes.data)
+    assert got == n.value
+    return idx, hams
+
+
 def aggregate_dir_u32(Cvol, dx, dy, P1, P2, buf, edges=False):
     h, w, D = Cvol.shape
     fn = lib().oracle_aggregate_dir_u32_edges if edges else lib().oracle_aggregate_dir_u32

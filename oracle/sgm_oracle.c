@@ -83,6 +83,43 @@ ORACLE_API void oracle_hamming_volume_u8(const uint32_t *cl, const uint32_t *cr,
                 C[((size_t)y * w + x) * D + d] = hamming_u32(cl[(size_t)y * w + x], cr[(size_t)y * w + x - d]);
 }
 
+/* core/hamming.c:104-116 hamming(): bit count of a xor b over ncodes bytes. */
+static uint16_t hamming_bytes(const uint8_t *a, const uint8_t *b, int ncodes)
+{
+    uint16_t s = 0;
+    for (int k = 0; k < ncodes; k++) {
+        uint8_t v = a[k] ^ b[k];
+        while (v) {
+            ++s;
+            v &= (uint8_t)(v - 1);
+        }
+    }
+    return s;
+}
+
+/* core/hamming.c:725-765 match_hamming_thres_prealloc (and :300-322 match_hamming_count when idx is
+ * NULL): for i, for j: distance <= ht -> idx gets (i, j), hams the distance; returns the count.
+ * cross != 0: core/hamming.c:810-839 crossmatch_hamming_prealloc (:385-407 the count): one set,
+ * j runs from i + 1. */
+ORACLE_API size_t oracle_match_hamming(const uint8_t *bs1, const uint8_t *bs2, long n1, long n2, int ht, int ncodes, int cross,
+                                       int *idx, uint16_t *hams)
+{
+    size_t posm = 0;
+    for (long i = 0; i < n1; i++)
+        for (long j = cross ? i + 1 : 0; j < n2; j++) {
+            const uint16_t h = hamming_bytes(bs1 + (size_t)i * ncodes, bs2 + (size_t)j * ncodes, ncodes);
+            if (h <= ht) {
+                if (idx) {
+                    idx[2 * posm] = (int)i;
+                    idx[2 * posm + 1] = (int)j;
+                    hams[posm] = h;
+                }
+                posm++;
+            }
+        }
+    return posm;
+}
+
 /* core/hamming.c:104-116 (hamming: per-byte bit-count table summed into a
  * uint16) and :215-236 (compute_hamming: dis[j*na + i] = hamming(a_i, b_j);
  * the 4/8/16-byte fast paths give the same numbers). */

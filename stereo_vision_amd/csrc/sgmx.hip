@@ -6,6 +6,7 @@
 #include "sgmx_kernels_v2.hpp"
 #include "sgmx_kernels_ns.hpp"
 #include "sgmx_kernels_eval.hpp"
+#include "sgmx_kernels_ham.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -1231,6 +1232,110 @@ int sgmx_hamming_matrix_u16(sgmx_ctx *c, uint16_t *dis, const uint8_t *a, const 
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, SGMX_ERR_HIP, std::string("hamming matrix: ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return SGMX_OK;
+}
+
+// Thresholded matching of binary signatures (core/hamming.c:300-322, 385-407, 725-765, 810-839).  cross: one
+// set against itself, pairs j > i only.  idx == nullptr: count only.
+static int ham_match(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, long n1, long n2, int ht, int ncodes, bool cross,
+                     int *idx, uint16_t *hams, size_t capacity, size_t *nptr)
+{
+    if (!c || !nptr || n1 < 0 || n2 < 0 || ncodes < 1 || n1 > 0x7fffffffL || n2 > 0x7fffffffL || (n1 > 0 && !bs1) ||
+        (!cross && n2 > 0 && !bs2) || (idx && !hams))
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
+    *nptr = 0;
+    if (n1 == 0 || n2 == 0)
+        return SGMX_OK;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    hipStream_t st = c->own_stream;
+    uint8_t *d_a = nullptr, *d_b = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    int *d_idx = nullptr;
+    uint16_t *d_h = nullptr;
+    unsigned long long total = 0;
+    auto cleanup = [&]() {
+        (void)hipFree(d_a);
+        if (d_b != d_a)
+            (void)hipFree(d_b);
+        (void)hipFree(d_cnt);
+        (void)hipFree(d_idx);
+        (void)hipFree(d_h);
+    };
+    hipError_t e = hipMalloc((void **)&d_a, (size_t)n1 * ncodes + 4);
+    if (e == hipSuccess) {
+        if (cross)
+            d_b = d_a;
+        else
+            e = hipMalloc((void **)&d_b, (size_t)n2 * ncodes + 4);
+    }
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_cnt, ((size_t)n1 + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_a, bs1, (size_t)n1 * ncodes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && !cross)
+        e = hipMemcpyAsync(d_b, bs2, (size_t)n2 * ncodes, hipMemcpyHostToDevice, st);
+    const dim3 grid((unsigned)((n1 + 3) / 4));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ham_count_kernel, grid, dim3(256), 0, st, d_a, d_b, (int)n1, (int)n2, ncodes, ht, cross ? 1 : 0, d_cnt);
+        hipLaunchKernelGGL(ham_scan_kernel, dim3(1), dim3(1024), 0, st, d_cnt, (int)n1, d_cnt + n1);
+        e = hipMemcpyAsync(&total, d_cnt + n1, sizeof(total), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP, std::string("hamming match: ") + hipGetErrorString(e));
+    }
+    *nptr = (size_t)total;
+    if (!idx || total == 0) {
+        cleanup();
+        return SGMX_OK;
+    }
+    if ((size_t)total > capacity) {
+        cleanup();
+        return fail(c, SGMX_ERR_INVALID_ARG, "hamming match: more matches than the caller's capacity (count first)");
+    }
+    e = hipMalloc((void **)&d_idx, (size_t)total * 2 * sizeof(int));
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_h, (size_t)total * sizeof(uint16_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ham_emit_kernel, grid, dim3(256), 0, st, d_a, d_b, (int)n1, (int)n2, ncodes, ht, cross ? 1 : 0, d_cnt,
+                           total, d_idx, d_h);
+        e = hipMemcpyAsync(idx, d_idx, (size_t)total * 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(hams, d_h, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP,
+                    std::string("hamming match: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_match_hamming_count(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, int n1, int n2, int ht, int ncodes, size_t *nptr)
+{
+    return ham_match(c, bs1, bs2, n1, n2, ht, ncodes, false, nullptr, nullptr, 0, nptr);
+}
+
+int sgmx_crossmatch_hamming_count(sgmx_ctx *c, const uint8_t *dbs, long n, int ht, int ncodes, size_t *nptr)
+{
+    return ham_match(c, dbs, dbs, n, n, ht, ncodes, true, nullptr, nullptr, 0, nptr);
+}
+
+int sgmx_match_hamming_thres_prealloc(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, int n1, int n2, int ht, int ncodes,
+                                      int *idx, uint16_t *hams, size_t capacity, size_t *nptr)
+{
+    if (!idx || !hams)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null output pointer");
+    return ham_match(c, bs1, bs2, n1, n2, ht, ncodes, false, idx, hams, capacity, nptr);
+}
+
+int sgmx_crossmatch_hamming_prealloc(sgmx_ctx *c, const uint8_t *dbs, long n, int ht, int ncodes, int *idx, uint16_t *hams,
+                                     size_t capacity, size_t *nptr)
+{
+    if (!idx || !hams)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null output pointer");
+    return ham_match(c, dbs, dbs, n, n, ht, ncodes, true, idx, hams, capacity, nptr);
 }
 
 static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16_t *raw)

@@ -173,6 +173,49 @@ class StereoSGM(Engine):
                                                     a.shape[1]))
         return out
 
+    def match_hamming_count(self, bs1, bs2, ht):
+        """match_hamming_count (core/hamming.h:75-76): number of pairs (i, j) with distance <= ht."""
+        a = np.ascontiguousarray(bs1, np.uint8)
+        b = np.ascontiguousarray(bs2, np.uint8)
+        n = C.c_size_t(0)
+        self.check(self.lib.sgmx_match_hamming_count(self.h, _ptr(a), _ptr(b), a.shape[0], b.shape[0], int(ht),
+                                                     a.shape[1], C.byref(n)))
+        return n.value
+
+    def crossmatch_hamming_count(self, dbs, ht):
+        """crossmatch_hamming_count (core/hamming.h:78-79): pairs j > i of one set."""
+        a = np.ascontiguousarray(dbs, np.uint8)
+        n = C.c_size_t(0)
+        self.check(self.lib.sgmx_crossmatch_hamming_count(self.h, _ptr(a), a.shape[0], int(ht), a.shape[1], C.byref(n)))
+        return n.value
+
+    def match_hamming_thres(self, bs1, bs2, ht):
+        """match_hamming_count + match_hamming_thres_prealloc (core/hamming.h:75-76, 90-92), the
+        reference's count / allocate / fill usage: returns idx (n, 2) int32 rows (i, j) in the
+        reference's loop order and the distances (n,) uint16."""
+        a = np.ascontiguousarray(bs1, np.uint8)
+        b = np.ascontiguousarray(bs2, np.uint8)
+        n = self.match_hamming_count(a, b, ht)
+        idx = np.empty((n, 2), np.int32)
+        hams = np.empty((n,), np.uint16)
+        got = C.c_size_t(0)
+        self.check(self.lib.sgmx_match_hamming_thres_prealloc(self.h, _ptr(a), _ptr(b), a.shape[0], b.shape[0], int(ht),
+                                                              a.shape[1], _ptr(idx), _ptr(hams), n, C.byref(got)))
+        assert got.value == n
+        return idx, hams
+
+    def crossmatch_hamming(self, dbs, ht):
+        """crossmatch_hamming_count + crossmatch_hamming_prealloc (core/hamming.h:78-79, 103-104)."""
+        a = np.ascontiguousarray(dbs, np.uint8)
+        n = self.crossmatch_hamming_count(a, ht)
+        idx = np.empty((n, 2), np.int32)
+        hams = np.empty((n,), np.uint16)
+        got = C.c_size_t(0)
+        self.check(self.lib.sgmx_crossmatch_hamming_prealloc(self.h, _ptr(a), a.shape[0], int(ht), a.shape[1], _ptr(idx),
+                                                             _ptr(hams), n, C.byref(got)))
+        assert got.value == n
+        return idx, hams
+
     def stages(self, H, W, index=0):
         m = self.margin
         h, w, D = H - 2 * m, W - 2 * m, self.params.disp_range

@@ -144,6 +144,28 @@ def test_hamming_matrix_vs_reference_build(oracle, ncodes):
     assert np.array_equal(mine, ref)
 
 
+@pytest.mark.parametrize("ncodes,ht", [(4, 12), (8, 26), (16, 56), (5, 17), (4, 0), (4, 32)])
+@pytest.mark.parametrize("cross", [False, True])
+def test_hamming_matchers_vs_reference_build(oracle, ncodes, ht, cross):
+    """oracle_match_hamming == core/hamming.c match_hamming_count / match_hamming_thres_prealloc /
+    crossmatch_hamming_count / crossmatch_hamming_prealloc (reference build): same matches, same order."""
+    rng = np.random.default_rng(ncodes * 100 + ht)
+    a = rng.integers(0, 256, size=(61, ncodes)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(45, ncodes)).astype(np.uint8)
+    b[7] = a[3]      # an exact match
+    a[20] = a[11]    # and one inside the set, for the cross form
+    idx, hams = oracle.match_hamming(a, b, ht, cross)
+    bb = a if cross else b
+    want = [(i, j, bin(int.from_bytes(bytes(a[i] ^ bb[j]), "little")).count("1"))
+            for i in range(len(a)) for j in range(i + 1 if cross else 0, len(bb))]
+    want = [(i, j, h) for i, j, h in want if h <= ht]
+    assert [(int(i), int(j), int(h)) for (i, j), h in zip(idx, hams)] == want
+    ref = oracle.ref_match_hamming(a, b, ht, cross)
+    if ref is None:
+        pytest.skip("oracle/_ref/libhamming_ref.so not built (reference tree not mounted)")
+    assert np.array_equal(idx, ref[0]) and np.array_equal(hams, ref[1])
+
+
 def test_median3_replicate_border(oracle):
     rng = np.random.default_rng(9)
     img = rng.integers(0, 65536, size=(6, 8)).astype(np.uint16)

@@ -48,6 +48,49 @@ def test_hamming_matrix(oracle, ncodes):
         assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("ncodes,ht", [(4, 10), (8, 24), (16, 52), (5, 16), (4, 0), (32, 300)])
+@pytest.mark.parametrize("cross", [False, True])
+def test_hamming_matchers(oracle, ncodes, ht, cross):
+    """match_hamming_count / _thres_prealloc and the crossmatch forms (core/hamming.h:73-104): same
+    matches in the same order as the restatement and as the reference's own core/hamming.c."""
+    rng = np.random.default_rng(ncodes + 7 * ht)
+    a = rng.integers(0, 256, size=(333, ncodes)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(209, ncodes)).astype(np.uint8)
+    b[17] = a[5]
+    a[200] = a[11]
+    e = make()
+    if cross:
+        n = e.crossmatch_hamming_count(a, ht)
+        idx, hams = e.crossmatch_hamming(a, ht)
+    else:
+        n = e.match_hamming_count(a, b, ht)
+        idx, hams = e.match_hamming_thres(a, b, ht)
+    want = oracle.match_hamming(a, b, ht, cross)
+    assert n == len(want[1])
+    assert np.array_equal(idx, want[0]) and np.array_equal(hams, want[1])
+    ref = oracle.ref_match_hamming(a, b, ht, cross)  # the reference's own core/hamming.c, when built
+    if ref is not None:
+        assert np.array_equal(idx, ref[0]) and np.array_equal(hams, ref[1])
+
+
+def test_hamming_matchers_capacity_and_empty(oracle):
+    """Too small a buffer: nothing written, the needed count reported, an error returned.  Empty sets: 0."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, size=(50, 4)).astype(np.uint8)
+    e = make()
+    n = e.match_hamming_count(a, a, 12)
+    assert n >= 50
+    idx = np.full((n, 2), -1, np.int32)
+    hams = np.zeros((n,), np.uint16)
+    got = C.c_size_t(0)
+    rc = e.lib.sgmx_match_hamming_thres_prealloc(e.h, a.ctypes.data, a.ctypes.data, 50, 50, 12, 4, idx.ctypes.data,
+                                                 hams.ctypes.data, n - 1, C.byref(got))
+    assert rc != 0 and got.value == n and (idx == -1).all()
+    assert e.match_hamming_count(a[:0], a, 12) == 0
+    assert e.crossmatch_hamming_count(a[:1], 32) == 0
+
+
 # ---------------------------------------------------------------- full pipeline, every stage
 CASES = [
     # H, W, D, wsz, P1, P2, paths
