@@ -465,15 +465,24 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
             t[j] = v[j];
         *reinterpret_cast<fvec *>(q) = t;
     };
+    // the volumes are streamed once per direction: non-temporal (835 -> 859 volumes/s at KITTI size)
+    auto ldv = [](const float *q) { return __builtin_nontemporal_load(reinterpret_cast<const fvec *>(q)); };
+    auto stv = [](float *q, const float (&v)[N]) {
+        fvec t;
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            t[j] = v[j];
+        __builtin_nontemporal_store(t, reinterpret_cast<fvec *>(q));
+    };
 
     float prior[N];
     {
         const size_t bo = (size_t)border_index(g.y0, g.x0, w, h) * Dp + loff;
         const fvec bl = ld(BLf + bo);
-        const fvec c = ld(Cf + off0 + loff);
+        const fvec c = ldv(Cf + off0 + loff);
         fvec s;
         if (!FIRST)
-            s = ld(Sf + off0 + loff);
+            s = ldv(Sf + off0 + loff);
         float sn[N];
 #pragma unroll
         for (int j = 0; j < N; j++) {
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
                 prior[j] = inf;
             sn[j] = FIRST ? prior[j] : s[j] + prior[j];
         }
-        st(Sf + off0 + loff, sn);
+        stv(Sf + off0 + loff, sn);
         st(BLf + bo, prior);
     }
     if (len == 1)
@@ -492,9 +501,9 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
 #pragma unroll
     for (int i = 0; i < PF; i++) {
         const int o = off0 + (1 + i < len ? 1 + i : len - 1) * stride;
-        cq[i] = ld(Cf + o + loff);
+        cq[i] = ldv(Cf + o + loff);
         if (!FIRST)
-            sq[i] = ld(Sf + o + loff);
+            sq[i] = ldv(Sf + o + loff);
     }
     const int xl = g.x0 + (len - 1) * a.dx, yl = g.y0 + (len - 1) * a.dy;
     const size_t bl_last = (size_t)border_index(yl, xl, w, h) * Dp;
@@ -508,9 +517,9 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
             s = sq[i];
         if (prefetch) {
             const int o2 = o + PF * stride;
-            cq[i] = ld(Cf + o2 + loff);
+            cq[i] = ldv(Cf + o2 + loff);
             if (!FIRST)
-                sq[i] = ld(Sf + o2 + loff);
+                sq[i] = ldv(Sf + o2 + loff);
         }
         const float left = __builtin_bit_cast(float, dpp<0x138>(__builtin_bit_cast(u32, inf), __builtin_bit_cast(u32, prior[N - 1])));
         const float right = __builtin_bit_cast(float, dpp<0x130>(__builtin_bit_cast(u32, inf), __builtin_bit_cast(u32, prior[0])));
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
 #pragma unroll
         for (int j = 0; j < N; j++)
             prior[j] = L[j];
-        st(Sf + o + loff, sn);
+        stv(Sf + o + loff, sn);
         if (g.edge) {
             const int x = g.x0 + t * a.dx, y = g.y0 + t * a.dy;
             st(BLf + (size_t)border_index(y, x, w, h) * Dp + loff, L);
