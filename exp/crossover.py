@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import stereo_vision_amd as sv
 from bench import synthetic_pair
-W, H, D = 1241, 376, 128
-l, r = synthetic_pair(1, H, W, 100)
-for B in (1, 2, 3, 4, 6, 8):
+W, H, D = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (1241, 376, 128)
+BS = [int(v) for v in sys.argv[4:]] or [1, 2, 3, 4, 6, 8]
+l, r = synthetic_pair(1, H, W, min(100, D - 4))
+for B in BS:
     L = torch.from_numpy(np.stack([l] * B)).cuda(); R = torch.from_numpy(np.stack([r] * B)).cuda()
     out = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
     res = []

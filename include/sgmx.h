@@ -65,9 +65,8 @@ typedef struct sgmx_params {
  * census path recomputes C from the census images and stores one byte per voxel and direction
  * instead; the results are identical.  penalty2 > 255 always uses the materialised form. */
 #define SGMX_FLAG_MATERIALIZE 1
-/* flags: by default a launch group of one pair (every single-pair call) runs on the
- * materialised kernels even when the volume-free formulation is eligible, because it is
- * latency-bound and those kernels have the shorter step; this flag disables that switch. */
+/* flags: accepted, no effect.  (Earlier builds ran launch groups of a few pairs on the materialised
+ * kernels and this flag switched that off; the volume-free kernels are now faster at every size.) */
 #define SGMX_FLAG_NO_SMALL_GROUPS 2
 
 typedef struct sgmx_ctx sgmx_ctx;

@@ -384,7 +384,7 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
         a.P2 = c->prm.penalty2;
         a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
         a.npairs = n;
-        const dim3 grid(8 * ((a.npaths + 15) / 16) * ((n + 7) / 8)); // 4 waves x 4 paths per workgroup, XCD-major pairs
+        const dim3 grid(8 * ((((a.npaths + 15) / 16) * n + 7) / 8)); // 4 waves x 4 paths per workgroup, 8 equal XCD chunks
         uint8_t *Ek = c->d_E + (size_t)k * c->bytes_E * c->prm.max_batch;
         ProfScope ps(c, SGMX_K_AGGREGATE, st);
         if (c->RP == 1)
@@ -643,7 +643,10 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->R = p.disp_range <= 128 ? 1 : (p.disp_range <= 256 ? 2 : 4);
     c->Dp = 128 * c->R;
     c->fast = p.penalty2 <= 255 && p.disp_range <= 256 && !(p.flags & SGMX_FLAG_MATERIALIZE);
-    c->small_n = (p.flags & SGMX_FLAG_NO_SMALL_GROUPS) ? 0 : 1; // measured at KITTI size: a single pair 1.09 ms here against 1.40 ms, two pairs 1.50 against 1.47
+    // No size switch any more: with the sweeps' work spread over all XCDs the volume-free kernels are the
+    // faster ones at every group size measured (one KITTI pair 1.12 against 1.09 ms, Tsukuba 0.39 / 0.51,
+    // one 4K pair 11.4 / 22.3 ms), so SGMX_FLAG_NO_SMALL_GROUPS is accepted and has no effect.
+    c->small_n = 0;
     c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : 8));
     c->DpF = 32 * c->RP;
     bool ok = hipSetDevice(p.device) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess &&

@@ -181,14 +181,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     const int lane = threadIdx.x & 63;
     const int q = lane & 15;
     // XCD-aware block -> (pair, path group) map: workgroups are dealt round-robin over the 8 XCDs, so
-    // block b lands on XCD b % 8; giving every XCD its own pairs (pair % 8 == b % 8) keeps the census
-    // images an XCD's L2 has to hold to the few pairs it is working on.  Speed only: any placement is correct.
+    // block b lands on XCD b % 8.  A multiple of 8 pairs: every XCD gets its own pairs (pair % 8 == b % 8),
+    // so the census images an XCD's L2 has to hold are those of the few pairs it is working on, and the 8
+    // XCDs write neighbouring E volumes.  Otherwise the pair-major list of (pair, group of 16 paths) items is
+    // cut into 8 equal contiguous chunks, one per XCD (one 4K pair spreads over the whole chip).
+    // Speed only: any placement is correct.
     const int ngroups = (a.npaths + 15) >> 4;
-    const int bi = blockIdx.x >> 3;
-    const int pair = (bi / ngroups) * 8 + (blockIdx.x & 7);
-    if (pair >= a.npairs)
-        return;
-    const int wave = (bi % ngroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = (int)(blockIdx.x & 7), bi = (int)(blockIdx.x >> 3);
+    int pair, grp;
+    if ((a.npairs & 7) == 0) {
+        pair = (bi / ngroups) * 8 + xcd;
+        grp = bi % ngroups;
+        if (pair >= a.npairs)
+            return;
+    } else {
+        const int items = ngroups * a.npairs, per = (items + 7) >> 3;
+        const int item = xcd * per + bi;
+        if (bi >= per || item >= items)
+            return;
+        pair = item / ngroups;
+        grp = item - pair * ngroups;
+    }
+    const int wave = grp * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave * 4 >= a.npaths)
         return;
     const int w = a.w, h = a.h, wp = a.wp;

@@ -200,8 +200,8 @@ def test_batch_chunks_equal_single(oracle):
 
 
 def test_adaptive_groups_mix_formulations(oracle):
-    """max_batch 5 over 9 pairs: a group of 5 (volume-free kernels) then one of 4, then a
-    single-pair call on the same context (materialised kernels): all bit-exact."""
+    """max_batch 5 over 9 pairs: a group of 5 then one of 4, then a single-pair call on the same
+    context, and the stage taps of that call: all bit-exact."""
     n, H, W = 9, 30, 140
     pairs = [synth_pair(300 + i, H, W, 50) for i in range(n)]
     e = make(disp_range=100, window_sz=5, max_batch=5)
