@@ -4,6 +4,7 @@
     python -m stereo_vision_amd.cli sgm_cnn LEFT.bin RIGHT.bin OUT PREFIX P1 P2 (sgm_cnn/main.cc:60-74)
     python -m stereo_vision_amd.cli batch_census LEFT_DIR RIGHT_DIR OUT [P1 P2] (scripts/run_sgm_batch_census.py)
     python -m stereo_vision_amd.cli batch_cnn DATA_DIR [P1 P2]                  (scripts/run_sgm_batch_cnn.py)
+    python -m stereo_vision_amd.cli grid_search DATA_DIR OUT_PREFIX [--p1 ..] [--p2 ..] (scripts/run_sgm_batch_grid_search.py)
 
 Same positional arguments as the reference; what it hard-codes (disp_range, window_sz) are options.
 The batch commands shard the pair list over the ranks of a torchrun launch (one process per GPU).
@@ -53,6 +54,17 @@ def main(argv=None):
     d.add_argument("P1", type=int, nargs="?", default=3)
     d.add_argument("P2", type=int, nargs="?", default=60)
     d.add_argument("--disp-range", type=int, default=255)
+    g = sub.add_parser("grid_search")
+    g.add_argument("data_dir")
+    g.add_argument("out_prefix")
+    g.add_argument("--p1", type=int, nargs="+", default=[4, 5, 6])
+    g.add_argument("--p2", type=int, nargs="+", default=[40, 45, 50, 55, 60])
+    g.add_argument("--start", type=int, default=0)
+    g.add_argument("--stop", type=int, default=193)
+    g.add_argument("--step", type=int, default=1)
+    g.add_argument("--disp-range", type=int, default=256)
+    g.add_argument("--window-sz", type=int, default=3)
+    g.add_argument("--batch", type=int, default=8)
     args = ap.parse_args(argv)
 
     from . import drivers
@@ -64,7 +76,14 @@ def main(argv=None):
         return 0
     rank, world, local = _dist()
     t0 = time.perf_counter()
-    if args.cmd == "batch_census":
+    if args.cmd == "grid_search":
+        res = drivers.run_grid_search(args.data_dir, args.out_prefix, args.p1, args.p2, args.start, args.stop, args.step,
+                                      args.disp_range, args.window_sz, rank, world, local, args.batch)
+        frames = sum(v[0] for v in res.values())
+        cks = 0
+        for v in res.values():
+            cks ^= v[1]
+    elif args.cmd == "batch_census":
         frames, cks = drivers.run_batch_census(args.left_dir, args.right_dir, args.out_folder, args.P1, args.P2,
                                                args.disp_range, args.window_sz, rank, world, local, args.batch)
     else:  # run_sgm_batch_cnn.py:22-23: representation/ in, depth/ out

@@ -5,6 +5,8 @@
     reconstruction/main/sgm_cnn/main.cc:11-74               sgm_cnn(left_desc, right_desc, out_dir, prefix, P1, P2)
     scripts/run_sgm_batch_census.py:14-34                   list_census_pairs, make_output_dirs, run_batch_census
     scripts/run_sgm_batch_cnn.py:22-42                      list_cnn_pairs, run_batch_cnn
+    scripts/run_sgm_batch_grid_search.py:14-54              list_numbered_pairs, grid_search_folder, run_grid_search
+    scripts/run_sgm_batch.py:51-66                          list_same_name_pairs (left/ and right/ hold equal names)
 
 Same file-selection rules, argv meaning and output files.  The reference runs one process per
 pair, strictly sequentially; here a rank takes a contiguous slice of the pair list (one process
@@ -80,6 +82,30 @@ def list_cnn_pairs(data_folder):
     prefix = name[:9]; right = prefix + "_right.bin".  Returns (left, right, prefix)."""
     names = sorted(f for f in os.listdir(data_folder) if isfile(join(data_folder, f)) and "left" in f)
     return [(join(data_folder, f), join(data_folder, f[:9] + "_right.bin"), f[:9]) for f in names]
+
+
+def list_numbered_pairs(data_folder, start_num=0, stop_num=193, frame_step=1, left_prefix="/image_0/",
+                        right_prefix="/image_1/", left_suffix="_10.png", right_suffix="_10.png", digits=6):
+    """scripts/run_sgm_batch_grid_search.py:14-31,49-53: frames start_num .. stop_num (inclusive) named
+    "%06d" + suffix under data_folder + prefix; plain string concatenation like the script."""
+    out = []
+    for i in range(start_num, stop_num + 1, frame_step):
+        num_str = "%0*d" % (digits, i)
+        out.append((data_folder + left_prefix + num_str + left_suffix, data_folder + right_prefix + num_str + right_suffix))
+    return out
+
+
+def grid_search_folder(out_folder_prefix, penalty1, penalty2):
+    """scripts/run_sgm_batch_grid_search.py:41: one result folder per grid point."""
+    return out_folder_prefix + "_" + str(penalty1) + "_" + str(penalty2) + "/data/"
+
+
+def list_same_name_pairs(data_folder):
+    """scripts/run_sgm_batch.py:51-60: every file of data_folder/left/, its partner has the same name in
+    data_folder/right/.  Sorted for determinism."""
+    left_dir, right_dir = data_folder + "/left/", data_folder + "/right/"
+    names = sorted(f for f in os.listdir(left_dir) if isfile(join(left_dir, f)))
+    return [(left_dir + f, right_dir + f) for f in names]
 
 
 def make_output_dirs(out_folder):
@@ -262,6 +288,47 @@ def run_batch_census(left_dir, right_dir, out_folder, P1=3, P2=60, disp_range=25
         frames += n
         i += n
     return frames, cks
+
+
+def _run_pairs(eng, pairs, out_folder, batch, write):
+    frames, cks = 0, 0
+    i = 0
+    while i < len(pairs):
+        group = [(read_gray(l), read_gray(r), l) for l, r in pairs[i:i + batch]]
+        n = 1
+        while n < len(group) and group[n][0].shape == group[0][0].shape:
+            n += 1
+        group = group[:n]
+        disp = eng.compute_batch(np.stack([g[0] for g in group]), np.stack([g[1] for g in group]))
+        for g, d in zip(group, disp):
+            print(g[2])
+            if write:
+                write_outputs(out_folder, stem(g[2]), d)
+            cks ^= fnv_u16(d)
+        frames += n
+        i += n
+    return frames, cks
+
+
+def run_grid_search(data_folder, out_folder_prefix, P1=(4, 5, 6), P2=(40, 45, 50, 55, 60), start_num=0, stop_num=193,
+                    frame_step=1, disp_range=256, window_sz=3, rank=0, world=1, device=0, batch=8, write=True, **naming):
+    """scripts/run_sgm_batch_grid_search.py:36-54: for every (P1, P2) of the grid, every numbered frame through
+    the census SGM binary (argv left right out_folder P1 P2, the sgm_single form) into its own result folder.
+    Each rank takes a contiguous slice of the frames of every grid point.  Returns {(P1, P2): (frames, checksum)}."""
+    pairs = list_numbered_pairs(data_folder, start_num, stop_num, frame_step, **naming)
+    lo, hi = shard_range(len(pairs), rank, world)
+    res = {}
+    for penalty1 in P1:
+        for penalty2 in P2:
+            out_folder = grid_search_folder(out_folder_prefix, penalty1, penalty2)
+            print(out_folder)
+            if rank == 0 and write:
+                make_output_dirs(out_folder)
+            eng = StereoSGM(StereoSGMParams(disp_range=disp_range, window_sz=window_sz, penalty1=penalty1,
+                                            penalty2=penalty2, device=device, max_batch=batch))
+            res[(penalty1, penalty2)] = _run_pairs(eng, pairs[lo:hi], out_folder, batch, write)
+            eng.close()
+    return res
 
 
 def run_batch_cnn(data_folder, out_folder, P1=3, P2=60, disp_range=255, rank=0, world=1, device=0, write=True):

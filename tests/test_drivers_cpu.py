@@ -45,6 +45,28 @@ def test_cnn_file_selection(tmp_path):
         ("000003_10_left.bin", "000003_10_right.bin", "000003_10")]
 
 
+def test_grid_search_naming():
+    """run_sgm_batch_grid_search.py:41,49-53: "%06d" frame numbers, stop_num inclusive, one folder per (P1, P2)."""
+    pairs = drivers.list_numbered_pairs("/data/training/", 0, 193)
+    assert len(pairs) == 194
+    assert pairs[0] == ("/data/training//image_0/000000_10.png", "/data/training//image_1/000000_10.png")
+    assert pairs[-1][0].endswith("/image_0/000193_10.png")
+    assert [os.path.basename(l) for l, _ in drivers.list_numbered_pairs("d", 3, 9, 3)] == [
+        "000003_10.png", "000006_10.png", "000009_10.png"]
+    assert drivers.grid_search_folder("/res/experiment", 4, 55) == "/res/experiment_4_55/data/"
+
+
+def test_same_name_file_selection(tmp_path):
+    """run_sgm_batch.py:51-60: every file of left/, partner of the same name in right/."""
+    (tmp_path / "left").mkdir(), (tmp_path / "right").mkdir()
+    for name in ("b.png", "a.png"):
+        (tmp_path / "left" / name).write_bytes(b"x")
+    (tmp_path / "left" / "sub").mkdir()
+    got = drivers.list_same_name_pairs(str(tmp_path))
+    assert [(os.path.basename(l), os.path.basename(r)) for l, r in got] == [("a.png", "a.png"), ("b.png", "b.png")]
+    assert all("/left/" in l and "/right/" in r for l, r in got)
+
+
 def test_output_dirs_and_names(tmp_path, capsys):
     out = str(tmp_path / "out")
     assert drivers.make_output_dirs(out) is True

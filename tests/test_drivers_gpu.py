@@ -108,6 +108,31 @@ def test_batch_census_driver_shards(oracle, tmp_path):
         assert np.array_equal(drivers.read_png16(str(out2 / "disparities" / (st + ".png"))), w), st
 
 
+def test_grid_search_driver(oracle, tmp_path):
+    """run_sgm_batch_grid_search over a 2 x 2 penalty grid and 3 numbered frames, as one rank and as two:
+    every result folder holds disparity maps bit-exact vs the oracle for its own (P1, P2)."""
+    from PIL import Image
+    data = tmp_path / "training"
+    (data / "image_0").mkdir(parents=True), (data / "image_1").mkdir()
+    frames = []
+    for i in range(3):
+        l, r = synth_pair(950 + i, 30, 100, 24)
+        Image.fromarray(l).save(str(data / "image_0" / ("%06d_10.png" % i)))
+        Image.fromarray(r).save(str(data / "image_1" / ("%06d_10.png" % i)))
+        frames.append((l, r))
+    prefix = str(tmp_path / "experiment")
+    res = drivers.run_grid_search(str(data), prefix, (3, 7), (20, 60), 0, 2, disp_range=32, window_sz=5, batch=2)
+    assert sorted(res) == [(3, 20), (3, 60), (7, 20), (7, 60)] and all(v[0] == 3 for v in res.values())
+    for (p1, p2) in res:
+        folder = drivers.grid_search_folder(prefix, p1, p2)
+        for i, (l, r) in enumerate(frames):
+            got = drivers.read_png16(os.path.join(folder, "disparities", "%06d_10.png" % i))
+            assert np.array_equal(got, oracle.sgm_census(l, r, 32, 5, p1, p2, 8)), (p1, p2, i)
+    ra = drivers.run_grid_search(str(data), prefix, (3,), (60,), 0, 2, disp_range=32, window_sz=5, rank=0, world=2, write=False)
+    rb = drivers.run_grid_search(str(data), prefix, (3,), (60,), 0, 2, disp_range=32, window_sz=5, rank=1, world=2, write=False)
+    assert (ra[(3, 60)][0], rb[(3, 60)][0]) == (2, 1) and (ra[(3, 60)][1] ^ rb[(3, 60)][1]) == res[(3, 60)][1]
+
+
 def test_float_volume_kitti_size(oracle):
     """BASELINE config 4: precomputed float data-cost volume, KITTI size 1241x376, D=128, 8 paths."""
     H, W, D = 376, 1241, 128
