@@ -44,6 +44,17 @@ class Mat {
 
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
+    // view of caller-owned pixels (cv::Mat's user-data constructor); a copy of a view owns its pixels
+    Mat(int r, int c, int type, void *ext, size_t step_bytes = 0)
+    {
+        if (type != MAT_8U && type != MAT_16U)
+            throw std::invalid_argument("sgmx::Mat: 8-bit or 16-bit single channel only");
+        type_ = type;
+        rows = r;
+        cols = c;
+        step = step_bytes ? step_bytes : (size_t)c * elem_size();
+        data = static_cast<unsigned char *>(ext);
+    }
     void create(int r, int c, int type)
     {
         if (type != MAT_8U && type != MAT_16U)
@@ -218,6 +229,15 @@ class StereoSGM {
                                           (int)(size_t)img.step),
                    "sgmx_gaussian_blur3_u8");
     }
+
+    // page-locked host memory for compute_batch buffers (sgmx_host_alloc / sgmx_host_free)
+    void *host_alloc(size_t bytes)
+    {
+        void *p = nullptr;
+        ctx_.check(sgmx_host_alloc(ctx_.get(), bytes, &p), "sgmx_host_alloc");
+        return p;
+    }
+    void host_free(void *p) { (void)sgmx_host_free(ctx_.get(), p); }
 
     sgmx_ctx *handle() const { return ctx_.get(); }
     const StereoSGMParams &params() const { return params_; }

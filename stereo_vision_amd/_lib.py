@@ -43,6 +43,8 @@ SYMBOLS = {
     "sgmx_census_u32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sgmx_hamming_volume_u8": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sgmx_hamming_matrix_u16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
+    "sgmx_host_alloc": (_i, [_vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "sgmx_host_free": (_i, [_vp, _vp]),
     "sgmx_match_hamming_count": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "sgmx_crossmatch_hamming_count": (_i, [_vp, _vp, C.c_long, _i, _i, C.POINTER(C.c_size_t)]),
     "sgmx_match_hamming_thres_prealloc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),

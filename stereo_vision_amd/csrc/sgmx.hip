@@ -708,6 +708,25 @@ int sgmx_compute_census_u8_dev(sgmx_ctx *c, int n, const uint8_t *d_left, const 
     return SGMX_OK;
 }
 
+int sgmx_host_alloc(sgmx_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || bytes == 0)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or zero size");
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    HIPCHK(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return SGMX_OK;
+}
+
+int sgmx_host_free(sgmx_ctx *c, void *ptr)
+{
+    if (!c)
+        return SGMX_ERR_INVALID_ARG;
+    if (ptr)
+        HIPCHK(c, hipHostFree(ptr));
+    return SGMX_OK;
+}
+
 int sgmx_compute_census_u8_batch(sgmx_ctx *c, int n, const uint8_t *left, const uint8_t *right, int W, int H,
                                  uint16_t *disp)
 {

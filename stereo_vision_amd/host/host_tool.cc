@@ -17,7 +17,7 @@ int main(int argc, char **argv)
         if (cmd == "gray8" && a.pos.size() == 3) { // any PNG -> 8-bit gray PNG (imread GRAYSCALE + imwrite)
             sgmx::png::write_gray(a.pos[2], sgmx::png::read_gray8(a.pos[1]));
         } else if (cmd == "gray16" && a.pos.size() == 3) { // 16-bit gray PNG -> 16-bit gray PNG
-            sgmx::png::write_gray(a.pos[2], sgmx::png::read_gray16(a.pos[1]), a.num("level", 6));
+            sgmx::png::write_gray(a.pos[2], sgmx::png::read_gray16(a.pos[1]), a.num("level", -1));
         } else if (cmd == "div256" && a.pos.size() == 3) { // convertTo(CV_8U, 1/256)
             sgmx::png::write_gray(a.pos[2], sgmx::host::convert_to_u8(sgmx::png::read_gray16(a.pos[1]), 1.0 / 256.0));
         } else if (cmd == "sat8" && a.pos.size() == 3) { // convertTo(CV_8U)

@@ -128,17 +128,34 @@ inline Raw decode(const std::string &path)
         const int ft = src[0];
         if (ft > 4)
             throw std::runtime_error(path + ": bad filter type");
-        for (size_t i = 0; i < r.rowbytes; i++) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
-            int v = src[i + 1];
-            switch (ft) {
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth(a, b, c); break;
-            default: break;
-            }
-            cur[i] = (unsigned char)v;
+        const unsigned char *in = src + 1;
+        const size_t n = r.rowbytes, head = bpp < n ? bpp : n;
+        switch (ft) {
+        case 0:
+            std::memcpy(cur, in, n);
+            break;
+        case 1:
+            for (size_t i = 0; i < head; i++)
+                cur[i] = in[i];
+            for (size_t i = head; i < n; i++)
+                cur[i] = (unsigned char)(in[i] + cur[i - bpp]);
+            break;
+        case 2:
+            for (size_t i = 0; i < n; i++)
+                cur[i] = (unsigned char)(in[i] + up[i]);
+            break;
+        case 3:
+            for (size_t i = 0; i < head; i++)
+                cur[i] = (unsigned char)(in[i] + (up[i] >> 1));
+            for (size_t i = head; i < n; i++)
+                cur[i] = (unsigned char)(in[i] + ((cur[i - bpp] + up[i]) >> 1));
+            break;
+        default:
+            for (size_t i = 0; i < head; i++)
+                cur[i] = (unsigned char)(in[i] + paeth(0, up[i], 0));
+            for (size_t i = head; i < n; i++)
+                cur[i] = (unsigned char)(in[i] + paeth(cur[i - bpp], up[i], up[i - bpp]));
+            break;
         }
     }
     return r;
@@ -219,10 +236,14 @@ inline void chunk(std::vector<unsigned char> &out, const char *type, const unsig
     put32(out, (uint32_t)crc32(crc32(0, Z_NULL, 0), &out[at], (uInt)(len + 4)));
 }
 
-// cv::imwrite(path, mat) for CV_8U / CV_16U single channel; per-row filter chosen by the usual
-// minimum-sum-of-absolute-differences heuristic, zlib level `level` (the reference's mains ask
-// for 9 where they pass compression_params, dense_stereo/main.cc:70-72,109).
-template <class MatT> inline void write_gray(const std::string &path, const MatT &m, int level = 6)
+// cv::imwrite(path, mat) for CV_8U / CV_16U single channel.
+//   level < 0 (default): what OpenCV's PNG encoder does when no compression parameter is passed, as in
+//     sgm_single/main.cc:55-56 and sgm_cnn/main.cc:49-50 -- the Sub filter on every row, Z_BEST_SPEED and the
+//     Z_RLE strategy ("tune parameters for speed", grfmt_png.cpp of the 2.4 / 3.x library).
+//   level 0..9: per-row filter chosen by the usual minimum-sum-of-absolute-differences heuristic and that zlib
+//     level (the mains that pass compression_params ask for 9, dense_stereo/main.cc:70-72,109).
+// The pixel values read back are the same either way; only the file size and the time differ.
+template <class MatT> inline void write_gray(const std::string &path, const MatT &m, int level = -1)
 {
     if (m.type() != MAT_8U && m.type() != MAT_16U)
         throw std::runtime_error("png::write_gray: 8- or 16-bit single channel only");
@@ -240,6 +261,17 @@ template <class MatT> inline void write_gray(const std::string &path, const MatT
             }
         else
             std::memcpy(cur.data(), src, rowbytes);
+        if (level < 0) {
+            raw.push_back(1); // Sub
+            const size_t at = raw.size();
+            raw.resize(at + rowbytes);
+            unsigned char *o = &raw[at];
+            for (size_t i = 0; i < rowbytes && i < (size_t)bps; i++)
+                o[i] = cur[i];
+            for (size_t i = bps; i < rowbytes; i++)
+                o[i] = (unsigned char)(cur[i] - cur[i - bps]);
+            continue;
+        }
         long best_sum = -1;
         int best_ft = 0;
         for (int ft = 0; ft < 5; ft++) {
@@ -270,8 +302,21 @@ template <class MatT> inline void write_gray(const std::string &path, const MatT
     }
     uLongf zlen = compressBound((uLong)raw.size());
     std::vector<unsigned char> z(zlen);
-    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), level) != Z_OK)
-        throw std::runtime_error("png::write_gray: deflate failed");
+    {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, level < 0 ? Z_BEST_SPEED : level, Z_DEFLATED, 15, 8, level < 0 ? Z_RLE : Z_DEFAULT_STRATEGY) != Z_OK)
+            throw std::runtime_error("png::write_gray: deflateInit2 failed");
+        zs.next_in = raw.data();
+        zs.avail_in = (uInt)raw.size();
+        zs.next_out = z.data();
+        zs.avail_out = (uInt)z.size();
+        const int rc = deflate(&zs, Z_FINISH);
+        zlen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END)
+            throw std::runtime_error("png::write_gray: deflate failed");
+    }
     std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     std::vector<unsigned char> hdr;
     put32(hdr, (uint32_t)m.cols);

@@ -11,6 +11,7 @@
 // environment) run one slice under an external launcher.  Within a worker, PNG decoding of the
 // next group and encoding of the previous one overlap the GPU work on the current one.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <dirent.h>
 #include <future>
@@ -153,56 +154,96 @@ Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
             });
             return grp;
         };
+        // Page-locked staging, two sets: while the engine works on set g & 1, the decoder threads of the next
+        // group and the encoder threads of the previous one run; the previous group's disparities stay in the
+        // other output buffer until its writer is done (it is joined before the buffer is used again).
+        struct Staging {
+            uint8_t *L = nullptr, *R = nullptr;
+            uint16_t *D = nullptr;
+            size_t pixels = 0;
+        } stg[2];
+        auto release = [&]() {
+            for (auto &s : stg) {
+                sgm.host_free(s.L);
+                sgm.host_free(s.R);
+                sgm.host_free(s.D);
+                s = Staging();
+            }
+        };
+        auto ensure = [&](Staging &s, size_t pixels) {
+            if (pixels <= s.pixels)
+                return;
+            sgm.host_free(s.L);
+            sgm.host_free(s.R);
+            sgm.host_free(s.D);
+            s.L = static_cast<uint8_t *>(sgm.host_alloc(pixels));
+            s.R = static_cast<uint8_t *>(sgm.host_alloc(pixels));
+            s.D = static_cast<uint16_t *>(sgm.host_alloc(pixels * 2));
+            s.pixels = pixels;
+        };
+        std::atomic<uint64_t> cks(0);
         std::future<Group> next;
         std::future<void> writer;
-        if (ngroups)
-            next = std::async(std::launch::async, load, (size_t)0);
-        for (size_t g = 0; g < ngroups; g++) {
-            Group grp = next.get();
-            if (g + 1 < ngroups)
-                next = std::async(std::launch::async, load, g + 1);
-            const int n = (int)grp.items.size();
-            auto disp = std::make_shared<std::vector<sgmx::Mat>>(n);
-            // runs of equal size go to the engine in one call
-            for (int i = 0; i < n;) {
-                const int W = grp.left[i].cols, H = grp.left[i].rows;
-                int j = i;
-                while (j < n && grp.left[j].cols == W && grp.left[j].rows == H && grp.right[j].cols == W &&
-                       grp.right[j].rows == H)
-                    j++;
-                if (j == i)
-                    throw std::runtime_error("left and right image differ in size: " + grp.items[i].left);
-                const size_t npix = (size_t)W * H;
-                std::vector<uint8_t> L(npix * (j - i)), R(npix * (j - i));
-                std::vector<uint16_t> D(npix * (j - i));
-                for (int k = i; k < j; k++) {
-                    std::memcpy(&L[npix * (k - i)], grp.left[k].data, npix);
-                    std::memcpy(&R[npix * (k - i)], grp.right[k].data, npix);
+        try {
+            if (ngroups)
+                next = std::async(std::launch::async, load, (size_t)0);
+            for (size_t g = 0; g < ngroups; g++) {
+                auto grp = std::make_shared<Group>(next.get());
+                if (g + 1 < ngroups)
+                    next = std::async(std::launch::async, load, g + 1);
+                const int n = (int)grp->items.size();
+                Staging &s = stg[g & 1];
+                size_t need = 0;
+                for (int k = 0; k < n; k++) {
+                    if (grp->left[k].cols != grp->right[k].cols || grp->left[k].rows != grp->right[k].rows)
+                        throw std::runtime_error("left and right image differ in size: " + grp->items[k].left);
+                    need += (size_t)grp->left[k].cols * grp->left[k].rows;
                 }
-                sgm.compute_batch(j - i, L.data(), R.data(), W, H, D.data());
-                for (int k = i; k < j; k++) {
-                    (*disp)[k].create(H, W, sgmx::MAT_16U);
-                    std::memcpy((*disp)[k].data, &D[npix * (k - i)], npix * 2);
+                ensure(s, need);
+                // pair k of the group sits at pixel offset off[k] of the staging buffers
+                auto off = std::make_shared<std::vector<size_t>>(n + 1, 0);
+                for (int k = 0; k < n; k++)
+                    (*off)[k + 1] = (*off)[k] + (size_t)grp->left[k].cols * grp->left[k].rows;
+                parallel_for(2 * n, o.threads, [&](int i) {
+                    const sgmx::Mat &m = (i & 1) ? grp->right[i / 2] : grp->left[i / 2];
+                    std::memcpy(((i & 1) ? s.R : s.L) + (*off)[i / 2], m.data, (size_t)m.cols * m.rows);
+                });
+                // runs of equal size go to the engine in one call
+                for (int i = 0; i < n;) {
+                    const int W = grp->left[i].cols, H = grp->left[i].rows;
+                    int j = i;
+                    while (j < n && grp->left[j].cols == W && grp->left[j].rows == H)
+                        j++;
+                    sgm.compute_batch(j - i, s.L + (*off)[i], s.R + (*off)[i], W, H, s.D + (*off)[i]);
+                    i = j;
                 }
-                i = j;
-            }
-            for (int k = 0; k < n; k++) {
-                std::cout << grp.items[k].left.substr(grp.items[k].left.rfind('/') + 1) << "\n";
-                c.checksum_xor ^= sgmx::host::fnv_u16((*disp)[k]);
-            }
-            c.frames += n;
-            if (writer.valid())
-                writer.get();
-            if (o.write) {
-                auto names = std::make_shared<std::vector<Item>>(grp.items);
-                writer = std::async(std::launch::async, [disp, names, &o]() {
-                    parallel_for((int)names->size(), o.threads,
-                                 [&](int k) { write_outputs(o.out, (*names)[k].prefix, (*disp)[k]); });
+                for (int k = 0; k < n; k++)
+                    std::cout << grp->items[k].left.substr(grp->items[k].left.rfind('/') + 1) << "\n";
+                c.frames += n;
+                if (writer.valid())
+                    writer.get();
+                uint16_t *D = s.D;
+                writer = std::async(std::launch::async, [grp, off, D, n, &o, &cks]() {
+                    parallel_for(n, o.threads, [&](int k) {
+                        const sgmx::Mat disp(grp->left[k].rows, grp->left[k].cols, sgmx::MAT_16U, D + (*off)[k]);
+                        cks.fetch_xor(sgmx::host::fnv_u16(disp));
+                        if (o.write)
+                            write_outputs(o.out, grp->items[k].prefix, disp);
+                    });
                 });
             }
+            if (writer.valid())
+                writer.get();
+        } catch (...) {
+            if (next.valid())
+                next.wait();
+            if (writer.valid())
+                writer.wait();
+            release();
+            throw;
         }
-        if (writer.valid())
-            writer.get();
+        release();
+        c.checksum_xor = cks.load();
     }
     c.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return c;
