@@ -44,7 +44,7 @@ struct sgmx_ctx {
     int W = 0, H = 0;          // census: full image; float: volume size
     int w = 0, h = 0, m = 0;   // cropped
     int mode = 0;              // 0 none, 1 census, 2 float, 3 float SGMStereo pipeline
-    bool fast = false;         // census path without C / S volumes (sgmx_kernels_v2.hpp): P2 <= 255, D <= 256
+    bool fast = false;         // census path without C / S volumes (sgmx_kernels_v2.hpp): P2 <= 255
     int RP = 4, DpF = 128;     // fast path: packed pairs per lane, padded disparity count 32 * RP
     int wp = 0;                // row pitch of the padded right census image (fast path)
     int small_n = 0;           // fast contexts: launch groups of <= small_n pairs take the materialised kernels
@@ -332,7 +332,7 @@ template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t 
 #ifndef SGMX_PF
 #define SGMX_PF 4
 #endif
-    constexpr int PF = RP == 8 ? 2 : SGMX_PF; // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
+    constexpr int PF = RP >= 8 ? 2 : SGMX_PF; // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
     if (first) {
         if (pad)
             hipLaunchKernelGGL((aggregate3_kernel<RP, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
@@ -393,8 +393,12 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
             launch_agg3<2>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
         else if (c->RP == 4)
             launch_agg3<4>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
-        else
+        else if (c->RP == 8)
             launch_agg3<8>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+        else if (c->RP == 12)
+            launch_agg3<12>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+        else
+            launch_agg3<16>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
         HIPCHK(c, hipGetLastError());
     }
     {
@@ -424,8 +428,12 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
             SGMX_WTA(2);
         else if (c->RP == 4)
             SGMX_WTA(4);
-        else
+        else if (c->RP == 8)
             SGMX_WTA(8);
+        else if (c->RP == 12)
+            SGMX_WTA(12);
+        else
+            SGMX_WTA(16);
 #undef SGMX_WTA
         HIPCHK(c, hipGetLastError());
     }
@@ -642,12 +650,12 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->prm = p;
     c->R = p.disp_range <= 128 ? 1 : (p.disp_range <= 256 ? 2 : 4);
     c->Dp = 128 * c->R;
-    c->fast = p.penalty2 <= 255 && p.disp_range <= 256 && !(p.flags & SGMX_FLAG_MATERIALIZE);
+    c->fast = p.penalty2 <= 255 && !(p.flags & SGMX_FLAG_MATERIALIZE);
     // No size switch any more: with the sweeps' work spread over all XCDs the volume-free kernels are the
     // faster ones at every group size measured (one KITTI pair 1.12 against 1.09 ms, Tsukuba 0.39 / 0.51,
     // one 4K pair 11.4 / 22.3 ms), so SGMX_FLAG_NO_SMALL_GROUPS is accepted and has no effect.
     c->small_n = 0;
-    c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : 8));
+    c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : (p.disp_range <= 256 ? 8 : (p.disp_range <= 384 ? 12 : 16))));
     c->DpF = 32 * c->RP;
     bool ok = hipSetDevice(p.device) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess &&
               hipStreamCreate(&c->copy_stream) == hipSuccess;
@@ -1410,8 +1418,12 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
                 hipLaunchKernelGGL(sums_tap_kernel<2>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
             else if (c->RP == 4)
                 hipLaunchKernelGGL(sums_tap_kernel<4>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
-            else
+            else if (c->RP == 8)
                 hipLaunchKernelGGL(sums_tap_kernel<8>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
+            else if (c->RP == 12)
+                hipLaunchKernelGGL(sums_tap_kernel<12>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
+            else
+                hipLaunchKernelGGL(sums_tap_kernel<16>, grid, dim3(256), 0, st, sa, index, (uint16_t *)tmp);
         } else if (mode == 1)
             hipLaunchKernelGGL(repitch_kernel<uint16_t>, dim3(nb), dim3(256), 0, st,
                                (const uint16_t *)((const uint8_t *)c->d_S + index * c->bytes_S), Dp, (uint16_t *)tmp, D,

@@ -1,4 +1,4 @@
-// sgmx_kernels_v2.hpp -- the census/Hamming fast path (P2 <= 255, D <= 256): no data-cost
+// sgmx_kernels_v2.hpp -- the census/Hamming fast path (P2 <= 255): no data-cost
 // volume and no summed-cost volume in HBM.
 //
 //   * The Hamming data cost C(p,d) = popcount(censL[p] ^ censR[p-d]) (stereo_sgm.cc:75-101,
@@ -75,6 +75,7 @@ __device__ __forceinline__ u32 row_min_u32(u32 x)
 
 // RP consecutive census words through a buffer descriptor (4-byte aligned)
 template <int RP> __device__ __forceinline__ void buf_load_win(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[RP]);
+// (RP = 1, 2, 4 below; the generic form after them serves 8, 12, 16)
 template <> __device__ __forceinline__ void buf_load_win<1>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[1])
 {
     o[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
@@ -89,11 +90,14 @@ template <> __device__ __forceinline__ void buf_load_win<4>(__amdgpu_buffer_rsrc
     const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
 }
-template <> __device__ __forceinline__ void buf_load_win<8>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[8])
+template <int RP> __device__ __forceinline__ void buf_load_win(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, u32 (&o)[RP])
 {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0);
-    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; o[4] = u.x; o[5] = u.y; o[6] = u.z; o[7] = u.w;
+    static_assert(RP % 4 == 0, "window loads come in 16-byte pieces");
+#pragma unroll
+    for (int m = 0; m < RP / 4; m++) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * m, soff, 0);
+        o[4 * m] = t.x; o[4 * m + 1] = t.y; o[4 * m + 2] = t.z; o[4 * m + 3] = t.w;
+    }
 }
 
 // RP packed pairs (each half <= 255) -> 2 RP bytes [lo0, hi0, lo1, hi1, ...] in NW = ceil(RP/2) dwords
@@ -119,9 +123,18 @@ __device__ __forceinline__ void buf_store_ev(__amdgpu_buffer_rsrc_t rs, unsigned
         t.x = v[0]; t.y = v[1];
         __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, E_STORE_AUX);
     } else {
-        u32x4 t;
-        t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, E_STORE_AUX);
+        constexpr int NW = RP / 2;
+#pragma unroll
+        for (int m = 0; m + 4 <= NW; m += 4) {
+            u32x4 t;
+            t.x = v[m]; t.y = v[m + 1]; t.z = v[m + 2]; t.w = v[m + 3];
+            __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff + 4 * m, soff, E_STORE_AUX);
+        }
+        if constexpr (NW % 4 == 2) {
+            u32x2 t;
+            t.x = v[NW - 2]; t.y = v[NW - 1];
+            __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff + 4 * (NW - 2), soff, E_STORE_AUX);
+        }
     }
 }
 // Hamming costs of a lane: wl[i] = censR[x - RP q - (RP-1) + i] (low half of register RP-1-i),
@@ -173,7 +186,7 @@ __device__ __forceinline__ LaneGeom lane_geometry(int p, int w, int h, int dx, i
 // and base' = base - T|s|, so soffset never goes negative; the descriptors are unbounded.
 // ---------------------------------------------------------------------------
 template <int RP, bool FIRST, bool HAS_PAD, int PF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4 : 3))) void aggregate3_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4 : (RP <= 8 ? 3 : 2)))) void aggregate3_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
                                                          uint8_t *__restrict__ E, uint16_t *__restrict__ BL,
                                                          uint16_t *__restrict__ SB, const Agg2Args a)
 {
@@ -457,36 +470,6 @@ struct SumArgs {
     int w, h, D, wp, N;
 };
 
-template <int RP> __device__ __forceinline__ void load_e_pairs(const uint8_t *p, u32 (&o)[RP]);
-template <> __device__ __forceinline__ void load_e_pairs<1>(const uint8_t *p, u32 (&o)[1])
-{
-    o[0] = __builtin_amdgcn_perm(0u, (u32) * reinterpret_cast<const unsigned short *>(p), 0x0c010c00u);
-}
-template <> __device__ __forceinline__ void load_e_pairs<2>(const uint8_t *p, u32 (&o)[2])
-{
-    const u32 v = *reinterpret_cast<const u32 *>(p);
-    o[0] = __builtin_amdgcn_perm(0u, v, 0x0c010c00u);
-    o[1] = __builtin_amdgcn_perm(0u, v, 0x0c030c02u);
-}
-template <> __device__ __forceinline__ void load_e_pairs<4>(const uint8_t *p, u32 (&o)[4])
-{
-    const uint2 v = *reinterpret_cast<const uint2 *>(p);
-    o[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u);
-    o[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
-    o[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u);
-    o[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
-}
-template <> __device__ __forceinline__ void load_e_pairs<8>(const uint8_t *p, u32 (&o)[8])
-{
-    const uint4 v = *reinterpret_cast<const uint4 *>(p);
-    const u32 d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        o[2 * k] = __builtin_amdgcn_perm(0u, d[k], 0x0c010c00u);
-        o[2 * k + 1] = __builtin_amdgcn_perm(0u, d[k], 0x0c030c02u);
-    }
-}
-
 // Raw inputs of one pixel's S for one lane: loaded one iteration ahead of their use.
 template <int RP> struct PixelRaw {
     u32 clv, wl[RP], wh[RP];
@@ -516,12 +499,13 @@ __device__ __forceinline__ void load_pixel(const SumArgs &a, int pair, int y, in
                 const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk));
                 r.ev[k][0] = v.x;
                 r.ev[k][1] = v.y;
-            } else {
-                const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(pk));
-                r.ev[k][0] = v.x;
-                r.ev[k][1] = v.y;
-                r.ev[k][2] = v.z;
-                r.ev[k][3] = v.w;
+            } else { // 8-byte pieces: the lane's 2 RP bytes start at a multiple of 8, not always of 16
+#pragma unroll
+                for (int m = 0; m < RP / 2; m += 2) {
+                    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + 4 * m));
+                    r.ev[k][m] = v.x;
+                    r.ev[k][m + 1] = v.y;
+                }
             }
         }
 }
@@ -612,15 +596,22 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int 
     const bool border_row = y == 0 || y == h - 1;
 
     auto clampx = [&](int x0) { const int x = x0 + r; return x < w ? x : w - 1; };
+    // the next 4 pixels' loads are in flight while these are summed, except for the widest layouts
+    // (RP >= 12, D > 256), where a second PixelRaw does not fit the register file
+    constexpr bool AHEAD = RP <= 8;
     PixelRaw<RP> cur;
-    if (wave * 4 < w)
+    if (AHEAD && wave * 4 < w)
         load_pixel<RP>(a, pair, y, clampx(wave * 4), q, cur);
     for (int x0 = wave * 4; x0 < w; x0 += 16) {
         const int x = x0 + r;
-        PixelRaw<RP> nxt;
+        PixelRaw<AHEAD ? RP : 1> nxt;
         const bool more = x0 + 16 < w;
-        if (more)
-            load_pixel<RP>(a, pair, y, clampx(x0 + 16), q, nxt);
+        if constexpr (AHEAD) {
+            if (more)
+                load_pixel<RP>(a, pair, y, clampx(x0 + 16), q, nxt);
+        } else {
+            load_pixel<RP>(a, pair, y, clampx(x0), q, cur);
+        }
         const bool full = x0 >= D - 1 && x0 + 3 < w; // every lane: pixel inside the row, every d <= x
         const int xc = x < w ? x : w - 1;
         const int xb = xc - RP * q;                  // x - d_lo of register 0
@@ -692,8 +683,10 @@ __global__ __launch_bounds__(256) void wta3_kernel(const SumArgs a, int P2, int 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier(); // the tile is overwritten by the next iteration
-        if (more)
-            cur = nxt;
+        if constexpr (AHEAD) {
+            if (more)
+                cur = nxt;
+        }
     }
     __syncthreads();
     for (int x = threadIdx.x; x < w; x += blockDim.x) {
