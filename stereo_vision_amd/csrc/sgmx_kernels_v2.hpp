@@ -57,11 +57,6 @@ struct Agg2Args {
 
 template <bool B> struct BoolC { static constexpr bool value = B; };
 
-// row_ror:N -- lane q of every 16-lane row reads lane (q - N) mod 16 of its row
-template <int N> __device__ __forceinline__ u32 row_ror(u32 v)
-{
-    return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x120 + N, 0xF, 0xF, true);
-}
 // Minimum over the 16 lanes of a row, left in every lane.  0xFFFFFFFF as `old` is the identity of
 // umin, which lets the compiler fold each step into one v_min_u32_dpp.
 __device__ __forceinline__ u32 row_min_u32(u32 x)
