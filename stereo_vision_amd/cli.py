@@ -5,6 +5,7 @@
     python -m stereo_vision_amd.cli batch_census LEFT_DIR RIGHT_DIR OUT [P1 P2] (scripts/run_sgm_batch_census.py)
     python -m stereo_vision_amd.cli batch_cnn DATA_DIR [P1 P2]                  (scripts/run_sgm_batch_cnn.py)
     python -m stereo_vision_amd.cli grid_search DATA_DIR OUT_PREFIX [--p1 ..] [--p2 ..] (scripts/run_sgm_batch_grid_search.py)
+    python -m stereo_vision_amd.cli create_rgbd_dataset -train|-test DATA_DIR OUT   (create_rgbd_dataset/main.cc:119-158)
 
 Same positional arguments as the reference; what it hard-codes (disp_range, window_sz) are options.
 The batch commands shard the pair list over the ranks of a torchrun launch (one process per GPU).
@@ -65,6 +66,9 @@ def main(argv=None):
     g.add_argument("--disp-range", type=int, default=256)
     g.add_argument("--window-sz", type=int, default=3)
     g.add_argument("--batch", type=int, default=8)
+    r = sub.add_parser("create_rgbd_dataset", prefix_chars="+")
+    for n in ("data_type", "data_dir", "out_folder"):
+        r.add_argument(n)
     args = ap.parse_args(argv)
 
     from . import drivers
@@ -73,6 +77,11 @@ def main(argv=None):
         return 0
     if args.cmd == "sgm_cnn":
         drivers.sgm_cnn(args.left, args.right, args.out_folder, args.prefix, args.P1, args.P2, args.disp_range)
+        return 0
+    if args.cmd == "create_rgbd_dataset":
+        if args.data_type not in ("-train", "-test"):
+            return 1  # main.cc:131-136
+        drivers.create_rgbd_dataset(args.data_type, args.data_dir, args.out_folder)
         return 0
     rank, world, local = _dist()
     t0 = time.perf_counter()

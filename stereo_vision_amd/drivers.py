@@ -7,6 +7,7 @@
     scripts/run_sgm_batch_cnn.py:22-42                      list_cnn_pairs, run_batch_cnn
     scripts/run_sgm_batch_grid_search.py:14-54              list_numbered_pairs, grid_search_folder, run_grid_search
     scripts/run_sgm_batch.py:51-66                          list_same_name_pairs (left/ and right/ hold equal names)
+    reconstruction/main/create_rgbd_dataset/main.cc:49-158  read_calib_kitti, fix_kitti_groundtruth, create_rgbd_dataset
 
 Same file-selection rules, argv meaning and output files.  The reference runs one process per
 pair, strictly sequentially; here a rank takes a contiguous slice of the pair list (one process
@@ -257,6 +258,64 @@ def dense_stereo(imagelist, source_folder, output_folder, disp_range=270, window
         tag = nm[9:len(nm) - 4] if len(nm) >= 14 else stem(nm)  # substr(9, size - 13), :106
         Image.fromarray(equalize_hist(np.minimum(disp, 255).astype(np.uint8))).save(output_folder + "img/disp_" + tag + ".png")
         out.append(disp)
+    return out
+
+
+# ---------------------------------------------------------------- RGB-D data set main
+def read_calib_kitti(path):
+    """core::FormatHelper::ReadCalibKitti (core/format_helper.cc:19-32,70-92): four "Pn:" rows of 12 numbers;
+    returns (grey_cam, color_cam), each [fx, fy, cx, cy, baseline] with baseline = |t_left - t_right| / fx."""
+    words = open(path).read().split()
+    P = []
+    for i in range(4):
+        P.append(np.array([float(v) for v in words[13 * i + 1:13 * i + 13]], np.float64).reshape(3, 4))
+
+    def params(pl, pr):
+        diff = pl[:, 3] - pr[:, 3]
+        return [pl[0, 0], pl[1, 1], pl[0, 2], pl[1, 2], float(np.sqrt((diff * diff).sum()) / pl[0, 0])]
+    return params(P[0], P[1]), params(P[2], P[3])
+
+
+def fix_kitti_groundtruth(rgb):
+    """FixKittiGroundtruth (create_rgbd_dataset/main.cc:29-47) on an (H, W, 3) RGB image: pure red -> blue,
+    everything else -> green."""
+    red = (rgb[..., 0] == 255) & (rgb[..., 1] == 0) & (rgb[..., 2] == 0)
+    out = np.zeros_like(rgb)
+    out[..., 1] = 255
+    out[red] = (0, 0, 255)
+    return out
+
+
+def create_rgbd_dataset(data_type, data_path, out_folder, P1=5, P2=60, disp_range=120, window_sz=5, device=0):
+    """create_rgbd_dataset -train/-test data_folder out_folder (main.cc:49-158): every file of data_path/left/
+    through the census SGM (disp_range 120, window 5, P1 5, P2 60; :73-83,134-135), depth in cm from the colour
+    camera's calibration (:12-27,92-95), and the four outputs per frame (:104-115).  Returns the depth images."""
+    from PIL import Image
+    if data_type not in ("-train", "-test"):
+        raise ValueError("data_type must be -train or -test")
+    have_gt = data_type == "-train"
+    left_dir = data_path + "/left/"
+    files = sorted(f for f in os.listdir(left_dir) if not f.startswith(".") and not os.path.isdir(join(left_dir, f)))
+    eng = StereoSGM(StereoSGMParams(disp_range=disp_range, window_sz=window_sz, penalty1=P1, penalty2=P2, device=device))
+    out = []
+    for name in files:
+        print(name)
+        _, color_cam = read_calib_kitti(data_path + "/calib/" + name[:-4] + ".txt")
+        left, right = read_gray(left_dir + name), read_gray(data_path + "/right/" + name)
+        disp = eng.compute(left, right)
+        depth = eng.depth_image(disp, color_cam[0], color_cam[4])
+        prefix = name[:-4]
+        Image.open(left_dir + name).convert("RGB").save(out_folder + "/" + prefix + "_colors.png")
+        write_png16(out_folder + "/" + prefix + "_depth.png", depth)
+        Image.fromarray(equalize_hist(to_u8_div256(disp))).save(out_folder + "/" + prefix + "_depth_visualization.png")
+        if have_gt:
+            pos = name.find("_")
+            gt_name = name[:pos] + "_road_" + name[pos + 1:]
+            gt = fix_kitti_groundtruth(np.asarray(Image.open(data_path + "/groundtruth/" + gt_name).convert("RGB")))
+        else:
+            gt = np.zeros(left.shape + (3,), np.uint8)
+        Image.fromarray(gt).save(out_folder + "/" + prefix + "_ground_truth.png")
+        out.append(depth)
     return out
 
 

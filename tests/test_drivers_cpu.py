@@ -67,6 +67,23 @@ def test_same_name_file_selection(tmp_path):
     assert all("/left/" in l and "/right/" in r for l, r in got)
 
 
+def test_calib_and_groundtruth_helpers(tmp_path):
+    """ReadCalibKitti (core/format_helper.cc:19-32,70-92) and FixKittiGroundtruth (create_rgbd_dataset/main.cc:29-47)."""
+    rows = ["P0: 721.5 0 609.5 0 0 721.5 172.8 0 0 0 1 0", "P1: 721.5 0 609.5 -387.5744 0 721.5 172.8 0 0 0 1 0",
+            "P2: 700.0 0 600.0 44.8 0 710.0 170.0 0.2 0 0 1 0.003", "P3: 700.0 0 600.0 -330.2 0 710.0 170.0 0.2 0 0 1 0.003"]
+    f = tmp_path / "um_000000.txt"
+    f.write_text("\n".join(rows) + "\n")
+    grey, color = drivers.read_calib_kitti(str(f))
+    assert grey[:4] == [721.5, 721.5, 609.5, 172.8] and abs(grey[4] - 387.5744 / 721.5) < 1e-12
+    assert color[:4] == [700.0, 710.0, 600.0, 170.0] and abs(color[4] - 375.0 / 700.0) < 1e-12
+    rgb = np.zeros((2, 3, 3), np.uint8)
+    rgb[0, 0] = (255, 0, 0)
+    rgb[0, 1] = (255, 0, 255)
+    rgb[1, 2] = (254, 0, 0)
+    out = drivers.fix_kitti_groundtruth(rgb)
+    assert tuple(out[0, 0]) == (0, 0, 255) and all(tuple(out[y, x]) == (0, 255, 0) for y, x in ((0, 1), (1, 2), (1, 1)))
+
+
 def test_output_dirs_and_names(tmp_path, capsys):
     out = str(tmp_path / "out")
     assert drivers.make_output_dirs(out) is True

@@ -133,6 +133,42 @@ def test_grid_search_driver(oracle, tmp_path):
     assert (ra[(3, 60)][0], rb[(3, 60)][0]) == (2, 1) and (ra[(3, 60)][1] ^ rb[(3, 60)][1]) == res[(3, 60)][1]
 
 
+def test_create_rgbd_dataset_driver(oracle, tmp_path):
+    """create_rgbd_dataset -train over two frames: depth bit-exact vs the oracle's CalculateDepthImage on the
+    oracle's disparity, colour copy, recoloured ground truth, equalised preview."""
+    from PIL import Image
+    data, out = tmp_path / "data", tmp_path / "out"
+    for d in ("left", "right", "calib", "groundtruth"):
+        (data / d).mkdir(parents=True)
+    out.mkdir()
+    calib = "P0: 700 0 60 0 0 700 20 0 0 0 1 0\nP1: 700 0 60 -370 0 700 20 0 0 0 1 0\n" \
+            "P2: 690 0 61 40 0 690 21 0 0 0 1 0\nP3: 690 0 61 -320 0 690 21 0 0 0 1 0\n"
+    frames = {}
+    for i in range(2):
+        l, r = synth_pair(970 + i, 40, 150, 60)
+        name = "um_%06d.png" % i
+        Image.fromarray(np.stack([l, l // 2, 255 - l], -1)).save(str(data / "left" / name))  # colour left image
+        Image.fromarray(r).save(str(data / "right" / name))
+        (data / "calib" / (name[:-4] + ".txt")).write_text(calib)
+        gt = np.zeros((40, 150, 3), np.uint8)
+        gt[5:20, 10:90] = (255, 0, 0)
+        Image.fromarray(gt).save(str(data / "groundtruth" / ("um_road_%06d.png" % i)))
+        frames[name[:-4]] = (drivers.read_gray(str(data / "left" / name)), r)
+    depths = drivers.create_rgbd_dataset("-train", str(data), str(out))
+    assert len(depths) == 2
+    for k, (prefix, (l, r)) in enumerate(sorted(frames.items())):
+        disp = oracle.sgm_census(l, r, 120, 5, 5, 60, 8)
+        want = oracle.depth_image(disp, 690.0, 360.0 / 690.0)
+        got = drivers.read_png16(str(out / (prefix + "_depth.png")))
+        assert np.array_equal(got, want) and np.array_equal(depths[k], want)
+        assert (got > 0).any()
+        gt = np.asarray(Image.open(str(out / (prefix + "_ground_truth.png"))))
+        assert tuple(gt[10, 50]) == (0, 0, 255) and tuple(gt[30, 100]) == (0, 255, 0)
+        vis = drivers.read_gray(str(out / (prefix + "_depth_visualization.png")))
+        assert np.array_equal(vis, drivers.equalize_hist(drivers.to_u8_div256(disp)))
+        assert os.path.exists(str(out / (prefix + "_colors.png")))
+
+
 def test_float_volume_kitti_size(oracle):
     """BASELINE config 4: precomputed float data-cost volume, KITTI size 1241x376, D=128, 8 paths."""
     H, W, D = 376, 1241, 128
