@@ -170,7 +170,7 @@ def main():
             avg_s = agg_ms / agg_n * 1e-3
             ach = per_launch_bytes / avg_s / 1e9
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_fast2_hbm_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
             if fast and os.path.exists(tfile):
                 t = json.load(open(tfile))
                 cfg = t.get("config", {})

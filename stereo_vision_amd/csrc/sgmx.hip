@@ -332,7 +332,10 @@ template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t 
 #ifndef SGMX_PF
 #define SGMX_PF 4
 #endif
-    constexpr int PF = RP >= 8 ? 2 : SGMX_PF; // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
+#ifndef SGMX_PF8
+#define SGMX_PF8 2
+#endif
+    constexpr int PF = RP >= 12 ? 2 : (RP == 8 ? SGMX_PF8 : SGMX_PF); // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
     if (first) {
         if (pad)
             hipLaunchKernelGGL((aggregate3_kernel<RP, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
