@@ -11,10 +11,16 @@ for d in ("image_0", "image_1"):
     os.makedirs(os.path.join(root, d), exist_ok=True)
 base = [synthetic_pair(100 + i, 376, 1241, 100) for i in range(8)]
 t = time.perf_counter()
+uniq = 64  # distinct files; the rest are hard links to them (same decode work per file)
 for i in range(n):
-    l, r = base[i % 8]
-    Image.fromarray(np.roll(l, i, axis=0)).save(os.path.join(root, "image_0", "%06d_10.png" % i), compress_level=1)
-    Image.fromarray(np.roll(r, i, axis=0)).save(os.path.join(root, "image_1", "%06d_10.png" % i), compress_level=1)
+    for d, k in (("image_0", 0), ("image_1", 1)):
+        dst = os.path.join(root, d, "%06d_10.png" % i)
+        if os.path.exists(dst):
+            os.remove(dst)
+        if i < uniq:
+            Image.fromarray(np.roll(base[i % 8][k], i, axis=0)).save(dst, compress_level=1)
+        else:
+            os.link(os.path.join(root, d, "%06d_10.png" % (i % uniq)), dst)
 print("wrote %d pairs in %.1f s" % (n, time.perf_counter() - t), flush=True)
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stereo_vision_amd", "bin", "sgm_batch")
 for extra in (["--no-write"], []):

@@ -83,6 +83,46 @@ def test_png16_round_trip(tmp_path, level):
     assert int(r.stdout.strip(), 16) == drivers.fnv_u16(d)
 
 
+@pytest.mark.parametrize("case", ["fibonacci", "constant", "two_values", "noise", "one_pixel", "filters"])
+def test_png_default_writer_huffman_block(tmp_path, case):
+    """The default writer's own deflate block (literals only, dynamic Huffman, lengths limited to 15 bits): Pillow
+    (zlib's inflate) must read back the pixels.  "fibonacci" makes the Sub-filtered bytes follow a Fibonacci
+    histogram, whose Huffman tree is deeper than 15 and takes the length-limiting path; "filters" feeds the reader
+    every PNG row filter (Pillow's adaptive choice on a smooth image) before the round trip."""
+    rng = np.random.default_rng(5)
+    if case == "fibonacci":
+        fib = [1, 1]
+        while len(fib) < 24:
+            fib.append(fib[-1] + fib[-2])
+        diffs = np.repeat(np.arange(24, dtype=np.int64), fib)
+        rng.shuffle(diffs)
+        W = 12000
+        diffs = np.resize(diffs, (len(diffs) // W + 1) * W).reshape(-1, W)
+        img = (np.cumsum(diffs, axis=1) % 256).astype(np.uint8)
+    elif case == "constant":
+        img = np.full((33, 70), 7, np.uint8)
+    elif case == "two_values":
+        img = (rng.integers(0, 2, (64, 64)) * 200).astype(np.uint8)
+    elif case == "noise":
+        img = rng.integers(0, 256, (376, 1241)).astype(np.uint8)
+    elif case == "one_pixel":
+        img = np.array([[9]], np.uint8)
+    else:
+        yy, xx = np.mgrid[0:120, 0:333]
+        img = ((np.sin(xx / 17.0) + np.cos(yy / 11.0)) * 60 + 128 + rng.integers(0, 3, (120, 333))).astype(np.uint8)
+    src, dst = tmp_path / "in.png", tmp_path / "out.png"
+    Image.fromarray(img).save(src, optimize=(case == "filters"))
+    r = run("host_tool", "gray8", src, dst)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.array(Image.open(dst)), img)
+    # and 16-bit: the same bytes as big-endian sample pairs
+    d16 = (img.astype(np.uint16) << 8) | np.roll(img, 1, axis=1)
+    drivers.write_png16(str(tmp_path / "d.png"), d16)
+    assert run("host_tool", "gray16", tmp_path / "d.png", tmp_path / "e.png").returncode == 0
+    assert np.array_equal(np.array(Image.open(tmp_path / "e.png")).astype(np.uint16), d16)
+    assert np.array_equal(drivers.read_png16(str(tmp_path / "e.png")), d16)
+
+
 def test_png_rejects_garbage(tmp_path):
     bad = tmp_path / "bad.png"
     bad.write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
