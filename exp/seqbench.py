@@ -28,7 +28,10 @@ for extra in (["--no-write"], []):
         cmd = [exe, "census", root + "/image_0", root + "/image_1", root + "/out", "3", "60", "--disp-range", "128", "--window-sz", "5",
                "--batch", "32", "--threads", str(threads)] + extra
         t = time.perf_counter()
-        out = subprocess.run(cmd, capture_output=True, text=True)
+        out = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SGMX_BATCH_TIMING="1"))
         dt = time.perf_counter() - t
         tail = [l for l in out.stdout.strip().splitlines() if "pairs" in l][-1:] or [out.stderr[-300:]]
         print("threads=%d %s: %.2f s wall, %.1f pairs/s | %s" % (threads, " ".join(extra) or "with PNG output", dt, n / dt, tail[0]), flush=True)
+        for l in out.stderr.splitlines():
+            if "timing" in l:
+                print("   ", l, flush=True)

@@ -50,6 +50,73 @@ int main(int argc, char **argv)
             for (float v : t.v)
                 sum += v;
             std::printf("%llu %llu %llu %.9g\n", (unsigned long long)t.H, (unsigned long long)t.W, (unsigned long long)t.K, sum);
+        } else if (cmd == "zfuzz" && a.pos.size() == 2) {
+            // The codec's own inflate and deflate against zlib: streams of five kinds of data from every zlib level,
+            // strategy and memory level must decode to the input; damaged, truncated and wrongly sized streams
+            // must be rejected (or, if a flipped bit happens to survive the Adler-32 check, decode to the input)
+            // without a write past the output; the own encoder's streams must decode with both inflaters.
+            uint64_t rs = 88172645463325252ull;
+            auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 16); };
+            const int rounds = std::atoi(a.pos[1].c_str());
+            long cases = 0, bad = 0;
+            const size_t sizes[] = {0, 1, 2, 100, 4097, 70000, 300000};
+            const int strategies[] = {Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED};
+            for (int round = 0; round < rounds; round++)
+                for (int kind = 0; kind < 5; kind++)
+                    for (int level = 0; level <= 9; level++)
+                        for (int strat : strategies)
+                            for (size_t size : sizes) {
+                                std::vector<unsigned char> src(size);
+                                for (size_t i = 0; i < size; i++)
+                                    src[i] = kind == 0   ? (unsigned char)rnd()
+                                             : kind == 1 ? (unsigned char)(rnd() % 4 == 0 ? rnd() : 0)
+                                             : kind == 2 ? (unsigned char)(i / 7 + rnd() % 3)
+                                             : kind == 3 ? (unsigned char)"abcabcabd"[i % 9]
+                                                         : (unsigned char)(rnd() % (1 + (i >> 8) % 40));
+                                std::vector<unsigned char> z(size + size / 8 + 4096);
+                                z_stream zs;
+                                std::memset(&zs, 0, sizeof(zs));
+                                if (deflateInit2(&zs, level, Z_DEFLATED, 15, 1 + (int)(cases % 9), strat) != Z_OK)
+                                    return 4;
+                                zs.next_in = src.data();
+                                zs.avail_in = (uInt)size;
+                                zs.next_out = z.data();
+                                zs.avail_out = (uInt)z.size();
+                                const int rc = deflate(&zs, Z_FINISH);
+                                const size_t zl = zs.total_out;
+                                deflateEnd(&zs);
+                                if (rc != Z_STREAM_END)
+                                    return 4;
+                                cases++;
+                                std::vector<unsigned char> out(size + 1, 0xAB);
+                                if (!sgmx::png::inflate_zlib_exact(z.data(), zl, out.data(), size) ||
+                                    (size && std::memcmp(out.data(), src.data(), size)) || out[size] != 0xAB)
+                                    bad++;
+                                if (size > 1 && sgmx::png::inflate_zlib_exact(z.data(), zl, out.data(), size - 1))
+                                    bad++;
+                                if (zl > 8) {
+                                    std::vector<unsigned char> zc(z.begin(), z.begin() + zl), o3(size + 1, 0xCD);
+                                    zc[2 + rnd() % (zl - 6)] ^= (unsigned char)(1u << (rnd() % 8));
+                                    const bool r = sgmx::png::inflate_zlib_exact(zc.data(), zl, o3.data(), size);
+                                    if (o3[size] != 0xCD || (r && size && std::memcmp(o3.data(), src.data(), size)))
+                                        bad++;
+                                    if (size && sgmx::png::inflate_zlib_exact(z.data(), zl - 3, o3.data(), size))
+                                        bad++;
+                                }
+                                if (level == 0 && strat == Z_DEFAULT_STRATEGY) { // own encoder, both decoders
+                                    const std::vector<unsigned char> own = sgmx::png::zlib_huffman_only(src.data(), size);
+                                    std::vector<unsigned char> o4(size + 1);
+                                    uLongf ol = (uLongf)o4.size();
+                                    if (uncompress(o4.data(), &ol, own.data(), (uLong)own.size()) != Z_OK || ol != size ||
+                                        (size && std::memcmp(o4.data(), src.data(), size)))
+                                        bad++;
+                                    if (!sgmx::png::inflate_zlib_exact(own.data(), own.size(), o4.data(), size) ||
+                                        (size && std::memcmp(o4.data(), src.data(), size)))
+                                        bad++;
+                                }
+                            }
+            std::printf("cases %ld bad %ld\n", cases, bad);
+            return bad ? 5 : 0;
         } else if (cmd == "shard" && a.pos.size() == 4) {
             long lo, hi;
             sgmx::host::shard_range(std::atol(a.pos[1].c_str()), std::atoi(a.pos[2].c_str()), std::atoi(a.pos[3].c_str()), &lo, &hi);

@@ -1,7 +1,7 @@
 // sgm_batch -- counterpart of scripts/run_sgm_batch_census.py:14-34 and run_sgm_batch_cnn.py:22-42.
 //   sgm_batch census LEFT_DIR RIGHT_DIR OUT_DIR [P1 P2] [--disp-range 256] [--window-sz 3]
 //   sgm_batch cnn DATA_DIR [P1 P2] [--disp-range 255]          (DATA_DIR/representation -> DATA_DIR/depth)
-// common: [--gpus N [--share-gpu: rehearsal, every worker on device 0]] [--rank R --world W] [--batch 8] [--threads 8] [--paths 8] [--token _10.png] [--no-write]
+// common: [--gpus N [--share-gpu: rehearsal, every worker on device 0]] [--rank R --world W] [--batch 8] [--threads 16: host worker threads per GPU worker, shared by decoders, copies and encoders] [--paths 8] [--token _10.png] [--no-write]
 //
 // Same file selection, output directories and per-pair outputs as the scripts, which start one
 // sgm_single / sgm_cnn process per pair, strictly one after the other.  Here the pair list is cut
@@ -13,6 +13,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <dirent.h>
 #include <future>
 #include <sys/wait.h>
@@ -76,26 +80,91 @@ void make_output_dirs(const std::string &out)
             throw std::runtime_error("cannot create " + out + sub);
 }
 
-template <class F> void parallel_for(int n, int threads, F f)
-{
-    threads = std::max(1, std::min(threads, n));
-    std::vector<std::thread> th;
-    std::vector<std::string> err(threads);
-    for (int t = 0; t < threads; t++)
-        th.emplace_back([&, t]() {
-            try {
-                for (int i = t; i < n; i += threads)
-                    f(i);
-            } catch (const std::exception &e) {
-                err[t] = e.what();
+// Worker threads of a slice: started once (after the fork into per-GPU workers), they serve the decoders, the
+// staging copies and the encoders alike, so the three stages share `threads` cores instead of each starting its
+// own set per group, and a thread's codec buffers (png_io.hpp: scratch) live from image to image.
+class Pool {
+  public:
+    explicit Pool(int threads)
+    {
+        for (int t = 0; t < std::max(1, threads); t++)
+            th_.emplace_back([this]() { work(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_)
+            t.join();
+    }
+    // f(0) .. f(n-1), handed to the workers one item at a time; returns when all are done and rethrows the first
+    // exception.  Items of an `urgent` job (the staging copies the engine call is waiting for) are taken before
+    // those of the jobs already queued.
+    template <class F> void run(int n, F f, bool urgent = false)
+    {
+        if (n <= 0)
+            return;
+        Job job;
+        job.n = n;
+        job.f = [&f](int i) { f(i); };
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (urgent)
+                q_.push_front(&job);
+            else
+                q_.push_back(&job);
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> l(m_);
+        job.finished.wait(l, [&job]() { return job.done == job.n; });
+        if (!job.err.empty())
+            throw std::runtime_error(job.err);
+    }
+
+  private:
+    struct Job {
+        std::function<void(int)> f;
+        int n = 0, next = 0, done = 0; // guarded by the pool's mutex
+        std::string err;
+        std::condition_variable finished;
+    };
+    void work()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        for (;;) {
+            cv_.wait(l, [this]() { return stop_ || !q_.empty(); });
+            if (q_.empty())
+                return;
+            Job *job = q_.front();
+            const int i = job->next++;
+            if (job->next >= job->n)
+                q_.pop_front(); // all items handed out; run() still waits for them to finish
+            const bool skip = !job->err.empty();
+            l.unlock();
+            std::string err;
+            if (!skip) {
+                try {
+                    job->f(i);
+                } catch (const std::exception &e) {
+                    err = e.what();
+                }
             }
-        });
-    for (auto &t : th)
-        t.join();
-    for (auto &e : err)
-        if (!e.empty())
-            throw std::runtime_error(e);
-}
+            l.lock();
+            if (!err.empty() && job->err.empty())
+                job->err = err;
+            if (++job->done == job->n)
+                job->finished.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Job *> q_;
+    bool stop_ = false;
+};
 
 void write_outputs(const std::string &out, const std::string &prefix, const sgmx::Mat &disp)
 {
@@ -118,8 +187,10 @@ struct Group {
 struct Options {
     bool cnn = false, write = true;
     std::string out;
-    int P1 = 3, P2 = 60, disp_range = 256, window_sz = 3, paths = 8, batch = 8, threads = 8;
+    int P1 = 3, P2 = 60, disp_range = 256, window_sz = 3, paths = 8, batch = 8, threads = 16;
 };
+
+int env_int(const char *name, int def);
 
 Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
 {
@@ -139,19 +210,25 @@ Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
     } else {
         recon::StereoSGMParams p = {o.disp_range, o.window_sz, o.P1, o.P2};
         recon::StereoSGM sgm(p, device, o.paths, o.batch);
+        Pool pool(o.threads);
         const size_t ngroups = (items.size() + o.batch - 1) / o.batch;
+        std::atomic<long> dec_us(0), load_us(0); // SGMX_BATCH_TIMING: decoder thread time, wall time of the group loads
         auto load = [&](size_t g) {
+            const auto tl0 = std::chrono::steady_clock::now();
             Group grp;
             const size_t lo = g * o.batch, hi = std::min(items.size(), lo + o.batch);
             grp.items.assign(items.begin() + lo, items.begin() + hi);
             grp.left.resize(hi - lo);
             grp.right.resize(hi - lo);
-            parallel_for((int)(2 * (hi - lo)), o.threads, [&](int i) {
+            pool.run((int)(2 * (hi - lo)), [&](int i) {
+                const auto td0 = std::chrono::steady_clock::now();
                 if (i & 1)
                     grp.right[i / 2] = sgmx::png::read_gray8(grp.items[i / 2].right);
                 else
                     grp.left[i / 2] = sgmx::png::read_gray8(grp.items[i / 2].left);
+                dec_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - td0).count();
             });
+            load_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tl0).count();
             return grp;
         };
         // Page-locked staging, two sets: while the engine works on set g & 1, the decoder threads of the next
@@ -187,10 +264,17 @@ Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
         try {
             if (ngroups)
                 next = std::async(std::launch::async, load, (size_t)0);
+            // SGMX_BATCH_TIMING=1: where the driving thread's time goes, on stderr at the end of the slice
+            const bool timing = env_int("SGMX_BATCH_TIMING", 0) != 0;
+            double t_wait_dec = 0, t_stage = 0, t_engine = 0, t_wait_wr = 0;
+            auto now = []() { return std::chrono::steady_clock::now(); };
+            auto since = [](std::chrono::steady_clock::time_point a) {
+                return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+            };
             for (size_t g = 0; g < ngroups; g++) {
+                auto tp = now();
                 auto grp = std::make_shared<Group>(next.get());
-                if (g + 1 < ngroups)
-                    next = std::async(std::launch::async, load, g + 1);
+                t_wait_dec += since(tp);
                 const int n = (int)grp->items.size();
                 Staging &s = stg[g & 1];
                 size_t need = 0;
@@ -204,10 +288,17 @@ Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
                 auto off = std::make_shared<std::vector<size_t>>(n + 1, 0);
                 for (int k = 0; k < n; k++)
                     (*off)[k + 1] = (*off)[k] + (size_t)grp->left[k].cols * grp->left[k].rows;
-                parallel_for(2 * n, o.threads, [&](int i) {
+                tp = now();
+                pool.run(2 * n, [&](int i) {
                     const sgmx::Mat &m = (i & 1) ? grp->right[i / 2] : grp->left[i / 2];
                     std::memcpy(((i & 1) ? s.R : s.L) + (*off)[i / 2], m.data, (size_t)m.cols * m.rows);
-                });
+                }, true);
+                t_stage += since(tp);
+                // the next group's decoders get the pool once this group's copies are through it, and then run
+                // beside the engine call
+                if (g + 1 < ngroups)
+                    next = std::async(std::launch::async, load, g + 1);
+                tp = now();
                 // runs of equal size go to the engine in one call
                 for (int i = 0; i < n;) {
                     const int W = grp->left[i].cols, H = grp->left[i].rows;
@@ -217,14 +308,17 @@ Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
                     sgm.compute_batch(j - i, s.L + (*off)[i], s.R + (*off)[i], W, H, s.D + (*off)[i]);
                     i = j;
                 }
+                t_engine += since(tp);
                 for (int k = 0; k < n; k++)
                     std::cout << grp->items[k].left.substr(grp->items[k].left.rfind('/') + 1) << "\n";
                 c.frames += n;
+                tp = now();
                 if (writer.valid())
                     writer.get();
+                t_wait_wr += since(tp);
                 uint16_t *D = s.D;
-                writer = std::async(std::launch::async, [grp, off, D, n, &o, &cks]() {
-                    parallel_for(n, o.threads, [&](int k) {
+                writer = std::async(std::launch::async, [grp, off, D, n, &o, &cks, &pool]() {
+                    pool.run(n, [&](int k) {
                         const sgmx::Mat disp(grp->left[k].rows, grp->left[k].cols, sgmx::MAT_16U, D + (*off)[k]);
                         cks.fetch_xor(sgmx::host::fnv_u16(disp));
                         if (o.write)
@@ -234,6 +328,12 @@ Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
             }
             if (writer.valid())
                 writer.get();
+            if (timing)
+                std::fprintf(stderr, "sgm_batch timing (s): wait for decoders %.3f, staging copies %.3f, engine calls %.3f, wait for writers %.3f\n",
+                             t_wait_dec, t_stage, t_engine, t_wait_wr);
+            if (timing)
+                std::fprintf(stderr, "sgm_batch timing (s): group loads %.3f wall, %.3f summed over the decoder threads\n",
+                             load_us.load() * 1e-6, dec_us.load() * 1e-6);
         } catch (...) {
             if (next.valid())
                 next.wait();
@@ -282,7 +382,7 @@ int main(int argc, char **argv)
         o.window_sz = a.num("window-sz", 3);
         o.paths = a.num("paths", 8);
         o.batch = std::max(1, a.num("batch", 8));
-        o.threads = std::max(1, a.num("threads", 8));
+        o.threads = std::max(1, a.num("threads", 16));
         o.write = !a.has("no-write");
         std::vector<Item> items;
         if (o.cnn) {

@@ -123,6 +123,15 @@ def test_png_default_writer_huffman_block(tmp_path, case):
     assert np.array_equal(drivers.read_png16(str(tmp_path / "e.png")), d16)
 
 
+def test_png_codec_inflate_and_deflate_against_zlib():
+    """host_tool zfuzz: the reader's own inflate on zlib streams of every level / strategy / memory level (stored, fixed
+    and dynamic blocks, long codes, overlapping matches), damaged and truncated streams, and the writer's own deflate
+    block through both inflaters."""
+    r = run("host_tool", "zfuzz", "1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout and "cases 1750" in r.stdout
+
+
 def test_png_rejects_garbage(tmp_path):
     bad = tmp_path / "bad.png"
     bad.write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
