@@ -50,7 +50,9 @@ enum {
  * struct SGMParams (reconstruction/base/sgm.h:18-23): the first four fields are
  * theirs, same meaning.  The rest are extensions; zero selects the default. */
 typedef struct sgmx_params {
-    int disp_range;  /* number of disparities D, d in [0, D); 2 <= D <= 512                    */
+    int disp_range;  /* number of disparities D, d in [0, D); 2 <= D <= 512.  Past D = 256 a winner
+                        d >= 256 gives 256 (d + ds) >= 65536: the output keeps the low 16 bits, as
+                        the reference's x86-64 builds do (stereo_sgm.h:309,312)      */
     int window_sz;   /* census window, odd, 1..31 (an even window reads past the image in the reference); m = (wsz-1)/2; ignored by the float path */
     int penalty1;    /* P1 >= 0                                                                 */
     int penalty2;    /* P2 >= 0; 36*255 + 8*P2 and P1 + 9*255 + P2 must stay below the uint16 guards */

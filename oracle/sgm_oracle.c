@@ -286,6 +286,18 @@ ORACLE_API int oracle_direction(int num_paths, int k, int *dx, int *dy)
     return -1;
 }
 
+/* static_cast<uint16_t>(double) at stereo_sgm.h:309,312 (sgm.h:324,327) is undefined once the value leaves
+ * [0, 65535] -- reachable with disp_range > 256 (value = 256 d) and, on the float path, with NaN / infinite
+ * sub-pixel terms.  What the reference's x86-64 builds do is cvttsd2si and keep the low 16 bits: the value wraps
+ * modulo 65536 while |r| < 2^31, and NaN / infinities / anything beyond give the low half of the "integer
+ * indefinite" 0x80000000, i.e. 0.  Restated explicitly so that the oracle does not itself rely on the cast. */
+static uint16_t cast_u16_like_x86(double r)
+{
+    if (!(fabs(r) < 2147483648.0))
+        return 0;
+    return (uint16_t)(uint32_t)(int32_t)r;
+}
+
 /* ------------------------------------------------------------------ */
 /* WTA + left-right check + subpixel                                   */
 /* ------------------------------------------------------------------ */
@@ -328,9 +340,9 @@ ORACLE_API void oracle_disparity_u16_from_u32(const uint32_t *S, int w, int h, i
                 else
                     ds = 0.5f * (cr - cl) / (cc - cr);
                 const float dsub = (float)d + ds; /* int + float is float arithmetic (:309) */
-                *o = (uint16_t)round(256.0 * (double)dsub);
+                *o = cast_u16_like_x86(round(256.0 * (double)dsub));
             } else {
-                *o = (uint16_t)round(256.0 * d);
+                *o = cast_u16_like_x86(round(256.0 * d));
             }
         }
     }
@@ -499,7 +511,7 @@ ORACLE_API void oracle_aggregate_dir_f32(const float *C, int w, int h, int D, in
 /* sgm.h:285-332 get_disparity_image_uint16 (CNN build): same decisions as the
  * census version but the output is h x w with NO padding (:291).  A NaN or
  * out-of-range subpixel value is undefined behaviour in the reference's
- * uint16 cast; here it yields 0 and is counted in *n_undefined (may be NULL)
+ * uint16 cast; here it goes through cast_u16_like_x86 and is counted in *n_undefined (may be NULL)
  * so tests can exclude those pixels. */
 ORACLE_API void oracle_disparity_u16_from_f32(const float *S, int w, int h, int D, uint16_t *out, int *n_undefined)
 {
@@ -536,13 +548,11 @@ ORACLE_API void oracle_disparity_u16_from_f32(const float *S, int w, int h, int 
                     ds = 0.5f * (cr - cl) / (cc - cr);
                 const float dsub = (float)d + ds;
                 const double r = round(256.0 * (double)dsub);
-                if (!(r >= 0.0 && r <= 65535.0)) {
-                    *o = 0;
+                if (!(r >= 0.0 && r <= 65535.0))
                     undef++;
-                } else
-                    *o = (uint16_t)r;
+                *o = cast_u16_like_x86(r);
             } else {
-                *o = (uint16_t)round(256.0 * d);
+                *o = cast_u16_like_x86(round(256.0 * d));
             }
         }
     }

@@ -590,14 +590,17 @@ __device__ __forceinline__ uint16_t subpixel_u16(int d, int D, float cl, float c
         const float ds = (float)((double)num / (double)den); // correctly rounded float quotient
         const float dsub = (float)d + ds;
         const double r = round(256.0 * (double)dsub);
-        if (!(r >= 0.0 && r <= 65535.0)) { // NaN / out of range: undefined cast in the reference
+        if (!(r >= 0.0 && r <= 65535.0)) {
+            // NaN / out of range (256 d >= 65536 once disp_range > 256): an undefined cast in the reference.  Its
+            // x86-64 builds convert with cvttsd2si and keep the low 16 bits: modulo 65536 while |r| < 2^31, and 0
+            // (low half of the "integer indefinite") for NaN, infinities and beyond.
             if (undefined)
                 *undefined = true;
-            return 0;
+            return fabs(r) < 2147483648.0 ? (uint16_t)(u32)(int)r : (uint16_t)0;
         }
         return (uint16_t)r;
     }
-    return (uint16_t)(256 * d);
+    return (uint16_t)(256 * d); // modulo 65536 like the cast above
 }
 
 template <int R>

@@ -216,3 +216,25 @@ def test_gaussian3_against_numpy(oracle):
             acc = (2 * k1 + k0) * rows
         want = np.minimum((acc + (1 << 15)) >> 16, 255).astype(np.uint8)
         assert np.array_equal(oracle.gaussian3(img, 0.7), want), shape
+
+
+def test_disparities_past_255_wrap_like_the_reference_builds(oracle):
+    """disp_range > 256: value = 256 (d + ds) leaves uint16 and the reference's static_cast<uint16_t>(double)
+    (stereo_sgm.h:309,312) is undefined; its x86-64 builds keep the low 16 bits.  The oracle restates that explicitly
+    (cast_u16_like_x86); this pins the restatement to the formula on every pixel whose winner is d >= 256."""
+    from conftest import synth_pair
+    H, W, D, wsz = 14, 700, 512, 3
+    left, right = synth_pair(H * 1000 + W + D, H, W, W // 2)
+    r = oracle.sgm_census(left, right, D, wsz, 5, 255, 8, taps=True)
+    S = r["S"].astype(np.int64)
+    m = (wsz - 1) // 2
+    raw = r["raw"][m:H - m, m:W - m]
+    am = S.argmin(axis=2)
+    big = np.argwhere((am >= 256) & (am < D - 1) & (raw != 0))
+    assert len(big) > 20
+    for y, x in big:
+        d = int(am[y, x])
+        cl, cc, cr = (np.float32(S[y, x, d - 1]), np.float32(S[y, x, d]), np.float32(S[y, x, d + 1]))
+        ds = np.float32(0.5) * (cr - cl) / ((cc - cl) if cr < cl else (cc - cr))
+        v = int(np.floor(256.0 * float(np.float32(d) + ds) + 0.5))  # std::round on a positive value
+        assert v >= 65536 and int(raw[y, x]) == v % 65536

@@ -106,6 +106,12 @@ CASES = [
     (21, 90, 270, 5, 7, 60, 8),
     (19, 70, 512, 3, 5, 5000, 8),
     (19, 70, 512, 3, 5, 255, 8),
+    # wider than D: the unmasked steady-state loops of the grouped layouts (8, 12, 16 packed pairs per lane)
+    (22, 430, 256, 5, 3, 60, 8),
+    (18, 470, 255, 3, 7, 60, 4),
+    (16, 520, 270, 5, 7, 60, 8),
+    (14, 700, 512, 3, 5, 255, 8),
+    (14, 640, 384, 5, 3, 60, 8),
     (12, 9, 16, 5, 0, 0, 8),
     (64, 7, 32, 3, 3, 7044, 8),
     (64, 7, 32, 3, 200, 255, 4),
