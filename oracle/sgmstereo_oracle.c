@@ -18,6 +18,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* float -> uint16 at sgm_stereo.cc:79-80 is undefined past 65535 (disparities >= 256); the reference's x86-64 builds
+ * keep the low 16 bits of cvttss2si's result (0 for NaN / infinities / |r| >= 2^31).  Same rule as
+ * cast_u16_like_x86 in sgm_oracle.c. */
+static uint16_t ns_cast_u16_like_x86(double r)
+{
+    if (!(fabs(r) < 2147483648.0))
+        return 0;
+    return (uint16_t)(uint32_t)(int32_t)r;
+}
+
 #define ORACLE_API __attribute__((visibility("default")))
 
 enum { NS_PATHS = 4 }; /* sgm_stereo.h:17 kNumPaths: paths per pass */
@@ -368,7 +378,7 @@ ORACLE_API int oracle_ns_compute(const float *left_cost, int w, int h, int D, in
             oracle_ns_interpolate(states, subpix, w, h);
             for (size_t i = 0; i < npix; i++) {
                 const float scaled = (float)round(subpix[i] * 256.0);
-                raw[i] = (uint16_t)scaled;
+                raw[i] = ns_cast_u16_like_x86((double)scaled);
             }
             oracle_median5_u16(raw, w, h, disp);
             if (left_disp_out)

@@ -582,6 +582,15 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
 //          in float32, 256.0 * (double), round half away, uint16.
 // Float keys: a monotone float->uint32 map in the high word of a 64-bit key.
 // ---------------------------------------------------------------------------
+// A floating-point value to uint16 the way the reference's x86-64 builds do where the C++ conversion is undefined
+// (value outside [0, 65535]: 256 d >= 65536 once disp_range > 256, NaN / infinite sub-pixel terms on the float
+// path): cvttsd2si and the low 16 bits, i.e. modulo 65536 while |r| < 2^31, else the low half of the "integer
+// indefinite" 0x80000000 = 0.  In range it is the plain conversion.
+__device__ __forceinline__ uint16_t cast_u16_like_x86(double r)
+{
+    return fabs(r) < 2147483648.0 ? (uint16_t)(u32)(int)r : (uint16_t)0;
+}
+
 __device__ __forceinline__ uint16_t subpixel_u16(int d, int D, float cl, float cc, float cr, bool *undefined)
 {
     if (d >= 1 && d < D - 1) {
@@ -590,15 +599,9 @@ __device__ __forceinline__ uint16_t subpixel_u16(int d, int D, float cl, float c
         const float ds = (float)((double)num / (double)den); // correctly rounded float quotient
         const float dsub = (float)d + ds;
         const double r = round(256.0 * (double)dsub);
-        if (!(r >= 0.0 && r <= 65535.0)) {
-            // NaN / out of range (256 d >= 65536 once disp_range > 256): an undefined cast in the reference.  Its
-            // x86-64 builds convert with cvttsd2si and keep the low 16 bits: modulo 65536 while |r| < 2^31, and 0
-            // (low half of the "integer indefinite") for NaN, infinities and beyond.
-            if (undefined)
-                *undefined = true;
-            return fabs(r) < 2147483648.0 ? (uint16_t)(u32)(int)r : (uint16_t)0;
-        }
-        return (uint16_t)r;
+        if (!(r >= 0.0 && r <= 65535.0) && undefined) // an undefined cast in the reference (see above)
+            *undefined = true;
+        return cast_u16_like_x86(r);
     }
     return (uint16_t)(256 * d); // modulo 65536 like the cast above
 }

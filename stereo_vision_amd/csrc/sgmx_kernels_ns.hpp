@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void ns_scale_kernel(const float *__restrict__
     if (i >= n)
         return;
     const float scaled = (float)__builtin_round((double)subpix[i] * 256.0);
-    out[i] = (uint16_t)scaled;
+    out[i] = cast_u16_like_x86((double)scaled); // past 65535 (D > 256) the reference's conversion is undefined: low 16 bits
 }
 
 // cv::medianBlur(img, img, 5) on CV_16U (sgm_stereo.cc:85): median of the 25 replicate-bordered

@@ -266,7 +266,8 @@ def _float_volume(seed, H, W, D, ties=False):
 
 
 @pytest.mark.parametrize("case", [(24, 70, 16, 8, False), (20, 150, 128, 8, False), (20, 150, 128, 8, True),
-                                  (17, 140, 100, 4, False), (14, 90, 255, 8, False), (11, 60, 300, 8, True)],
+                                  (17, 140, 100, 4, False), (14, 90, 255, 8, False), (11, 60, 300, 8, True),
+                                  (9, 640, 300, 8, False)],  # wider than D: winners past d = 255 (low 16 bits of 256 d)
                          ids=lambda c: "x".join(map(str, c)))
 def test_float_cost_path(oracle, case):
     H, W, D, paths, ties = case
