@@ -138,6 +138,34 @@ def test_pipeline_stages_bit_exact(oracle, case, flags):
     assert np.array_equal(e.data_cost_image(H, W), oracle.data_cost_wta(want["C"], m))
 
 
+def _random_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        wsz = int(rng.choice([1, 3, 5, 7]))
+        H = int(rng.integers(wsz, 48)) + 1
+        W = int(rng.integers(wsz, 420)) + 1
+        D = int(rng.choice([int(rng.integers(2, 513)), 16, 32, 33, 64, 65, 128, 129, 256, 257, 384, 385, 512]))
+        P1 = int(rng.integers(0, 40))
+        P2 = int(rng.integers(P1, 256))
+        out.append((H, W, D, wsz, P1, P2, int(rng.choice([4, 8]))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_configs(48, 20261110), ids=lambda c: "x".join(map(str, c)))
+def test_seeded_random_configurations(oracle, case):
+    """Sizes, disparity ranges, windows and penalties drawn from a seeded generator (layout boundaries of the packed
+    lanes included): final disparity of the default formulation against the oracle, and the materialised
+    formulation on the same input."""
+    H, W, D, wsz, P1, P2, paths = case
+    left, right = synth_pair(H * 977 + W * 13 + D, H, W, max(1, min(D, W // 2)))
+    want = oracle.sgm_census(left, right, D, wsz, P1, P2, paths)
+    for flags in (2, 1):
+        e = make(disp_range=D, window_sz=wsz, penalty1=P1, penalty2=P2, num_paths=paths, flags=flags)
+        assert np.array_equal(e.compute(left, right), want), "flags=%d" % flags
+        e.close()
+
+
 @pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
 @pytest.mark.parametrize("shape", [(5, 5), (6, 40), (40, 6), (5, 300), (6, 6), (7, 5), (5, 7)])
 def test_degenerate_shapes(oracle, shape, flags):
