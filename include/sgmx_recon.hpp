@@ -279,6 +279,13 @@ class SGM {
         sgmx::DescriptorTensor l, r;
         sgmx::LoadRepresentationFromFile(left_desc_path, &l);
         sgmx::LoadRepresentationFromFile(right_desc_path, &r);
+        return ComputeFromDescriptors<MatT>(l, r);
+    }
+
+    // Compute() for descriptor tensors the caller has already loaded (a batch driver reads the next pair's
+    // files while this pair is on the GPU).
+    template <class MatT = DefaultMat> MatT ComputeFromDescriptors(const sgmx::DescriptorTensor &l, const sgmx::DescriptorTensor &r)
+    {
         if (l.H != r.H || l.W != r.W || l.K != r.K)
             throw sgmx::Error(SGMX_ERR_INVALID_ARG, "SGM::Compute: left and right descriptor tensors differ in size");
         MatT disp;

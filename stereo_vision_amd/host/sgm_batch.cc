@@ -199,13 +199,45 @@ Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
     if (o.cnn) {
         recon::SGMParams p = {o.disp_range, 0, o.P1, o.P2};
         recon::SGM sgm(p, device, o.paths);
-        for (auto &it : items) {
-            std::cout << it.left.substr(it.left.rfind('/') + 1) << std::endl;
-            const sgmx::Mat disp = sgm.Compute<sgmx::Mat>(it.left, it.right);
-            if (o.write)
-                write_outputs(o.out, it.prefix, disp);
-            c.checksum_xor ^= sgmx::host::fnv_u16(disp);
-            c.frames++;
+        // The two descriptor files of a pair (hundreds of MB at KITTI size) are read by two threads, one pair
+        // ahead of the GPU; the previous pair's PNG files are written meanwhile.
+        struct Loaded {
+            sgmx::DescriptorTensor l, r;
+        };
+        auto load = [&](size_t i) {
+            auto p = std::make_shared<Loaded>();
+            auto fr = std::async(std::launch::async, [&, i]() { sgmx::LoadRepresentationFromFile(items[i].right, &p->r); });
+            sgmx::LoadRepresentationFromFile(items[i].left, &p->l);
+            fr.get();
+            return p;
+        };
+        std::future<std::shared_ptr<Loaded>> next;
+        std::future<void> writer;
+        if (!items.empty())
+            next = std::async(std::launch::async, load, (size_t)0);
+        try {
+            for (size_t i = 0; i < items.size(); i++) {
+                const Item &it = items[i];
+                std::cout << it.left.substr(it.left.rfind('/') + 1) << std::endl;
+                const std::shared_ptr<Loaded> cur = next.get();
+                if (i + 1 < items.size())
+                    next = std::async(std::launch::async, load, i + 1);
+                auto disp = std::make_shared<sgmx::Mat>(sgm.ComputeFromDescriptors<sgmx::Mat>(cur->l, cur->r));
+                c.checksum_xor ^= sgmx::host::fnv_u16(*disp);
+                c.frames++;
+                if (writer.valid())
+                    writer.get();
+                if (o.write)
+                    writer = std::async(std::launch::async, [disp, &o, &it]() { write_outputs(o.out, it.prefix, *disp); });
+            }
+            if (writer.valid())
+                writer.get();
+        } catch (...) {
+            if (next.valid())
+                next.wait();
+            if (writer.valid())
+                writer.wait();
+            throw;
         }
     } else {
         recon::StereoSGMParams p = {o.disp_range, o.window_sz, o.P1, o.P2};
