@@ -170,18 +170,26 @@ def main():
             avg_s = agg_ms / agg_n * 1e-3
             ach = per_launch_bytes / avg_s / 1e9
             traffic = None
+            step_bytes = None
             tfile = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
             if fast and os.path.exists(tfile):
                 t = json.load(open(tfile))
                 cfg = t.get("config", {})
                 if cfg == {"batch": B, "width": W, "height": H, "disp": D, "paths": args.paths, "wsz": args.wsz}:
                     traffic = t["kernels"]["aggregate3_kernel"]["hbm_bytes_per_launch"]
+                    k = t["kernels"]
+                    # HBM bytes of one whole step (PMC passes under profiles/): census + N sweeps + WTA + median
+                    step_bytes = (k["census4_kernel"]["hbm_bytes_per_launch"] + args.paths * traffic +
+                                  k["wta3_kernel"]["hbm_bytes_per_launch"] + k["median3_kernel"]["hbm_bytes_per_launch"])
             roof = {"bound": "hbm", "kernel": "aggregate3_kernel" if fast else "aggregate_u16_kernel",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "avg_launch_ms": round(agg_ms / agg_n, 4),
                     "alg_bytes_per_launch": per_launch_bytes,
                     "hbm_GBs_from_traffic": round(traffic / avg_s / 1e9, 1) if traffic else None,
                     "whole_pipeline_alg_GBs": round(alg_total * fps / world / 1e9, 1),
+                    "step_hbm_bytes_from_pmc": step_bytes,
+                    "step_hbm_GBs": round(step_bytes / (dt / args.steps) / 1e9, 1) if step_bytes else None,
+                    "step_hbm_frac_of_peak": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if step_bytes else None,
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stats.items()}}
         out["roofline"] = roof
 
