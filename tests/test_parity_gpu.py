@@ -315,6 +315,52 @@ def test_float_cost_path(oracle, case):
     assert int(np.sum(disp != want["disp"])) <= 9 * want["n_undefined"]
 
 
+def _random_float_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        H = int(rng.integers(1, 40))
+        W = int(rng.integers(2, 380))
+        D = int(rng.choice([int(rng.integers(2, 513)), 64, 65, 128, 129, 256, 257, 512]))
+        P1 = int(rng.integers(0, 20))
+        out.append((H, W, D, P1, int(rng.integers(P1, 200)), int(rng.choice([4, 8])), bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_float_configs(24, 77), ids=lambda c: "x".join(map(str, c)))
+def test_seeded_random_float_volumes(oracle, case):
+    """Float-volume path on seeded random sizes / ranges / penalties (with and without exact ties): aggregated
+    costs within north_star's 1e-5 (bit-exact in practice), disparities identical apart from the reference's
+    undefined pixels."""
+    H, W, D, P1, P2, paths, ties = case
+    C = _float_volume(H * 131 + W + D, H, W, D, ties)
+    e = make(sv.SGM, disp_range=D, penalty1=P1, penalty2=P2, num_paths=paths)
+    disp = e.compute_cost(C)
+    want = oracle.sgm_cost_f32(C, P1, P2, paths, taps=True)
+    S = e.stages(H, W)["S"]
+    finite = np.isfinite(want["S"])
+    assert np.array_equal(np.isfinite(S), finite)
+    assert np.array_equal(S[finite], want["S"][finite])
+    assert int(np.sum(disp != want["disp"])) <= 9 * want["n_undefined"]
+    e.close()
+
+
+def test_seeded_random_batches(oracle):
+    """Launch groups of random pair counts (1 .. 11, contexts of random max_batch) through the host batch entry point:
+    every pair equals its own oracle result, whatever its place in a group."""
+    rng = np.random.default_rng(99)
+    for trial in range(6):
+        H, W = int(rng.integers(8, 40)), int(rng.integers(20, 200))
+        D = int(rng.choice([16, 48, 128, 200]))
+        n, mb = int(rng.integers(1, 12)), int(rng.integers(1, 9))
+        pairs = [synth_pair(1000 * trial + i, H, W, max(1, min(D, W // 2))) for i in range(n)]
+        e = make(disp_range=D, window_sz=5, penalty1=3, penalty2=60, max_batch=mb)
+        got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+        for i, (l, r) in enumerate(pairs):
+            assert np.array_equal(got[i], oracle.sgm_census(l, r, D, 5, 3, 60, 8)), (trial, i, n, mb)
+        e.close()
+
+
 # ---------------------------------------------------------------- caller-side pre-filter
 @pytest.mark.parametrize("shape", [(376, 1241), (37, 53), (1, 9), (9, 1), (1, 1), (2, 300)])
 @pytest.mark.parametrize("sigma", [0.7, 0.0, 1.5])
