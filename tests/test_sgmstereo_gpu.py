@@ -51,6 +51,27 @@ def test_pipeline_stages(oracle, case):
     check(oracle, e, C, P1, P2, thr)
 
 
+def _random_ns_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        P1 = int(rng.integers(0, 12))
+        D = int(rng.choice([int(rng.integers(2, 257)), 64, 65, 128, 129, 256]))
+        W = D + int(rng.integers(0, 120))  # the pipeline needs width >= disparity range (the reference reads out of bounds otherwise)
+        out.append((int(rng.integers(1, 36)), W, D, P1, int(rng.integers(P1 + 1, 120)), int(rng.integers(0, 3))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_ns_configs(16, 5), ids=lambda c: "x".join(map(str, c)))
+def test_seeded_random_configurations(oracle, case):
+    H, W, D, P1, P2, thr = case
+    C, _ = smooth_volume(H * 7 + W + D, H, W, D)
+    e = sv.SGMStereo()
+    e.SetSmoothnessCostParameters(P1, P2)
+    e.SetConsistencyThreshold(thr)
+    check(oracle, e, C, P1, P2, thr)
+
+
 def test_speckles_occlusions_and_mismatches_all_occur(oracle):
     """A volume built so that every branch runs: small islands (speckles), a foreground block that
     occludes background (o), disagreeing right view (m)."""
