@@ -117,6 +117,51 @@ int main(int argc, char **argv)
                             }
             std::printf("cases %ld bad %ld\n", cases, bad);
             return bad ? 5 : 0;
+        } else if (cmd == "pool" && a.pos.size() == 2) {
+            // The batch driver's worker pool: jobs submitted from several threads at once (as the decoder, staging and
+            // writer stages do), urgent jobs among them, every item run exactly once, exceptions reported to the
+            // submitting thread only.
+            sgmx::host::Pool pool(std::atoi(a.pos[1].c_str()));
+            std::atomic<long> sum(0), caught(0);
+            std::vector<std::thread> submitters;
+            for (int t = 0; t < 6; t++)
+                submitters.emplace_back([&, t]() {
+                    for (int round = 0; round < 40; round++) {
+                        const int n = 1 + (t * 7 + round * 3) % 37;
+                        std::vector<int> hits(n, 0);
+                        try {
+                            pool.run(n, [&](int i) {
+                                hits[i]++;
+                                sum += i;
+                                if (t == 5 && round % 8 == 0 && i == n / 2)
+                                    throw std::runtime_error("item failed");
+                            }, t % 2 == 1);
+                            for (int h : hits)
+                                if (h != 1)
+                                    sum += 1000000000L; // every item exactly once
+                        } catch (const std::exception &) {
+                            caught++;
+                        }
+                    }
+                });
+            for (auto &t : submitters)
+                t.join();
+            long want = 0;
+            for (int t = 0; t < 6; t++)
+                for (int round = 0; round < 40; round++) {
+                    const int n = 1 + (t * 7 + round * 3) % 37;
+                    if (!(t == 5 && round % 8 == 0))
+                        want += (long)n * (n - 1) / 2;
+                }
+            // failing jobs add some of their items before the exception stops them: leave them out of the sum check
+            long failing = 0;
+            for (int round = 0; round < 40; round += 8) {
+                const int n = 1 + (5 * 7 + round * 3) % 37;
+                failing += (long)n * (n - 1) / 2;
+            }
+            const long got = sum.load();
+            std::printf("caught %ld sum %s\n", caught.load(), got >= want && got <= want + failing ? "ok" : "BAD");
+            return caught.load() == 5 && got >= want && got <= want + failing ? 0 : 5;
         } else if (cmd == "shard" && a.pos.size() == 4) {
             long lo, hi;
             sgmx::host::shard_range(std::atol(a.pos[1].c_str()), std::atoi(a.pos[2].c_str()), std::atoi(a.pos[3].c_str()), &lo, &hi);

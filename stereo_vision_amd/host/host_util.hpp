@@ -5,6 +5,13 @@
 #ifndef SGMX_HOST_UTIL_HPP
 #define SGMX_HOST_UTIL_HPP
 
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -273,6 +280,92 @@ inline void shard_range(long n, int r, int w, long *lo, long *hi)
     *lo = r * per < n ? r * per : n;
     *hi = *lo + per < n ? *lo + per : n;
 }
+
+// Worker threads of a slice: started once (after the fork into per-GPU workers), they serve the decoders, the
+// staging copies and the encoders alike, so the three stages share `threads` cores instead of each starting its
+// own set per group, and a thread's codec buffers (png_io.hpp: scratch) live from image to image.
+class Pool {
+  public:
+    explicit Pool(int threads)
+    {
+        for (int t = 0; t < std::max(1, threads); t++)
+            th_.emplace_back([this]() { work(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_)
+            t.join();
+    }
+    // f(0) .. f(n-1), handed to the workers one item at a time; returns when all are done and rethrows the first
+    // exception.  Items of an `urgent` job (the staging copies the engine call is waiting for) are taken before
+    // those of the jobs already queued.
+    template <class F> void run(int n, F f, bool urgent = false)
+    {
+        if (n <= 0)
+            return;
+        Job job;
+        job.n = n;
+        job.f = [&f](int i) { f(i); };
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (urgent)
+                q_.push_front(&job);
+            else
+                q_.push_back(&job);
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> l(m_);
+        job.finished.wait(l, [&job]() { return job.done == job.n; });
+        if (!job.err.empty())
+            throw std::runtime_error(job.err);
+    }
+
+  private:
+    struct Job {
+        std::function<void(int)> f;
+        int n = 0, next = 0, done = 0; // guarded by the pool's mutex
+        std::string err;
+        std::condition_variable finished;
+    };
+    void work()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        for (;;) {
+            cv_.wait(l, [this]() { return stop_ || !q_.empty(); });
+            if (q_.empty())
+                return;
+            Job *job = q_.front();
+            const int i = job->next++;
+            if (job->next >= job->n)
+                q_.pop_front(); // all items handed out; run() still waits for them to finish
+            const bool skip = !job->err.empty();
+            l.unlock();
+            std::string err;
+            if (!skip) {
+                try {
+                    job->f(i);
+                } catch (const std::exception &e) {
+                    err = e.what();
+                }
+            }
+            l.lock();
+            if (!err.empty() && job->err.empty())
+                job->err = err;
+            if (++job->done == job->n)
+                job->finished.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Job *> q_;
+    bool stop_ = false;
+};
 
 } // namespace host
 } // namespace sgmx

@@ -132,6 +132,15 @@ def test_png_codec_inflate_and_deflate_against_zlib():
     assert "bad 0" in r.stdout and "cases 1750" in r.stdout
 
 
+@pytest.mark.parametrize("threads", [1, 4, 16])
+def test_worker_pool(threads):
+    """The batch driver's pool (host_util.hpp): concurrent submitters, urgent jobs, every item once, exceptions
+    delivered to the submitting thread."""
+    r = run("host_tool", "pool", threads)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "caught 5 sum ok" in r.stdout
+
+
 def test_png_rejects_garbage(tmp_path):
     bad = tmp_path / "bad.png"
     bad.write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
