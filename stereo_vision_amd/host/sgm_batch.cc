@@ -1,7 +1,7 @@
 // sgm_batch -- counterpart of scripts/run_sgm_batch_census.py:14-34 and run_sgm_batch_cnn.py:22-42.
 //   sgm_batch census LEFT_DIR RIGHT_DIR OUT_DIR [P1 P2] [--disp-range 256] [--window-sz 3]
 //   sgm_batch cnn DATA_DIR [P1 P2] [--disp-range 255]          (DATA_DIR/representation -> DATA_DIR/depth)
-// common: [--gpus N [--share-gpu: rehearsal, every worker on device 0]] [--rank R --world W] [--batch 8] [--threads 16: host worker threads per GPU worker, shared by decoders, copies and encoders] [--paths 8] [--token _10.png] [--no-write]
+// common: [--gpus N [--share-gpu: rehearsal, every worker on device 0]] [--rank R --world W] [--batch B: pairs per launch group, default sized from the first image (up to 32 within 48 GB of device scratch)] [--threads 16: host worker threads per GPU worker, shared by decoders, copies and encoders] [--paths 8] [--token _10.png] [--no-write]
 //
 // Same file selection, output directories and per-pair outputs as the scripts, which start one
 // sgm_single / sgm_cnn process per pair, strictly one after the other.  Here the pair list is cut
@@ -99,13 +99,29 @@ struct Group {
 struct Options {
     bool cnn = false, write = true;
     std::string out;
-    int P1 = 3, P2 = 60, disp_range = 256, window_sz = 3, paths = 8, batch = 8, threads = 16;
+    int P1 = 3, P2 = 60, disp_range = 256, window_sz = 3, paths = 8, batch = 0, threads = 16;
 };
 
 int env_int(const char *name, int def);
 
-Counters run_slice(const std::vector<Item> &items, const Options &o, int device)
+// Pairs per launch group when --batch is not given: 32 fill the chip at KITTI size; larger images take
+// what fits 48 GB of the engine's scratch (8 byte volumes of w h Dp bytes per pair dominate it).
+int default_batch(const std::vector<Item> &items, const Options &o)
 {
+    if (items.empty())
+        return 1;
+    const sgmx::png::Raw &hdr = sgmx::png::decode(items[0].left);
+    const int Dp = o.disp_range <= 32 ? 32 : (o.disp_range <= 64 ? 64 : (o.disp_range <= 128 ? 128 : (o.disp_range <= 256 ? 256 : (o.disp_range <= 384 ? 384 : 512))));
+    const double per_pair = (double)hdr.W * hdr.H * ((double)o.paths * Dp + 24.0);
+    const double fit = 48e9 / per_pair;
+    return (int)std::max(1.0, std::min(32.0, fit));
+}
+
+Counters run_slice(const std::vector<Item> &items, const Options &o_in, int device)
+{
+    Options o = o_in;
+    if (!o.cnn && o.batch <= 0)
+        o.batch = default_batch(items, o);
     Counters c;
     const auto t0 = std::chrono::steady_clock::now();
     if (o.cnn) {
@@ -325,7 +341,7 @@ int main(int argc, char **argv)
         o.disp_range = a.num("disp-range", o.cnn ? 255 : 256);
         o.window_sz = a.num("window-sz", 3);
         o.paths = a.num("paths", 8);
-        o.batch = std::max(1, a.num("batch", 8));
+        o.batch = std::max(0, a.num("batch", 0)); // 0: from the first image, in run_slice
         o.threads = std::max(1, a.num("threads", 16));
         o.write = !a.has("no-write");
         std::vector<Item> items;
