@@ -680,8 +680,11 @@ __global__ __launch_bounds__(256) void wta_f32_kernel(const float *__restrict__ 
         rkey[x] = ~0ull;
     __syncthreads();
     typedef float fvec __attribute__((ext_vector_type(N)));
+    // the next pixel's costs are in flight while this one's keys are built
+    fvec nxt = *reinterpret_cast<const fvec *>(Srow + (size_t)(wave < w ? wave : w - 1) * Dp + lane * N);
     for (int x = wave; x < w; x += 4) {
-        const fvec s = *reinterpret_cast<const fvec *>(Srow + (size_t)x * Dp + lane * N);
+        const fvec s = nxt;
+        nxt = *reinterpret_cast<const fvec *>(Srow + (size_t)(x + 4 < w ? x + 4 : w - 1) * Dp + lane * N);
         unsigned long long best = ~0ull;
 #pragma unroll
         for (int j = 0; j < N; j++) {
