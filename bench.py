@@ -27,6 +27,38 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD = 1024          # 256 CUs x 4 SIMDs
+# Issue cost of the sweeps' instruction mix, measured by exp/valu_rate.hip (profiles/r02_valu_issue.txt): every
+# opcode of the step but v_xor_b32 costs 4.25 cycles per wave64 instruction per SIMD at 4 waves per SIMD
+# (v_pk_*_u16, v_bcnt, DPP, v_lshl_add, v_perm, v_alignbit, v_pk_maximum3_f16), v_xor_b32 2.5.
+VALU_CYCLES_SLOW, VALU_CYCLES_FAST = 4.25, 2.5
+
+
+def kernel_src_sha256():
+    """Hash of the sources libsgmx.so is built from: profiles/*_hbm_traffic.json carries the hash it was measured
+    at, and `roofline.traffic` is only reported when it is the hash of this tree."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "stereo_vision_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "include", "sgmx.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def find_traffic(cfg):
+    """Newest profiles/r*_hbm_traffic.json measured on this configuration AND on these kernel sources."""
+    import glob
+    sha = kernel_src_sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except ValueError:
+            continue
+        if t.get("config") == cfg and t.get("kernel_src_sha256") == sha:
+            return t, os.path.basename(f)
+    return None, None
 
 
 def box3(a):
@@ -52,11 +84,52 @@ def synthetic_pair(seed, H, W, max_disp):
     return to8(left), to8(right)
 
 
+def secondary_figures(eng, sv, args, Lh, Rh, B, W, H):
+    """Figures beside the headline, same workload, clearly labelled (never `value`):
+    host_batch_pairs_per_s -- page-locked host buffers -> sgmx_compute_census_u8_batch -> host (PCIe both ways);
+    single_pair_ms -- one pair per sgmx_compute_census_u8 call, the reference's own call pattern
+    (reconstruction/main/sgm_single/main.cc:43-44), pageable host buffers."""
+    import ctypes as C
+    lib = eng.lib
+    sec = {}
+    n, nfull = B, W * H
+    ptrs = []
+    try:
+        for nbytes in (n * nfull, n * nfull, n * nfull * 2):
+            p = C.c_void_p()
+            eng.check(lib.sgmx_host_alloc(eng.h, nbytes, C.byref(p)))
+            ptrs.append(p)
+        hl = np.ctypeslib.as_array(C.cast(ptrs[0], C.POINTER(C.c_uint8)), (n, H, W))
+        hr = np.ctypeslib.as_array(C.cast(ptrs[1], C.POINTER(C.c_uint8)), (n, H, W))
+        hl[:] = Lh
+        hr[:] = Rh
+        reps = 3
+        eng.check(lib.sgmx_compute_census_u8_batch(eng.h, n, ptrs[0], ptrs[1], W, H, ptrs[2]))  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.check(lib.sgmx_compute_census_u8_batch(eng.h, n, ptrs[0], ptrs[1], W, H, ptrs[2]))
+        sec["host_batch_pairs_per_s"] = round(reps * n / (time.perf_counter() - t0), 1)
+        sec["host_batch_note"] = "%d pairs per call from page-locked host memory, results back to the host" % n
+    finally:
+        for p in ptrs:
+            lib.sgmx_host_free(eng.h, p)
+    one = sv.StereoSGM(sv.StereoSGMParams(disp_range=args.disp, window_sz=args.wsz, penalty1=args.p1, penalty2=args.p2,
+                                          num_paths=args.paths, device=eng.params.device, max_batch=1))
+    one.compute(Lh[0], Rh[0])
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one.compute(Lh[0], Rh[0])
+    sec["single_pair_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+    one.close()
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="stereo pairs per GPU per step (one launch group)")
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--height", type=int, default=376)
@@ -69,7 +142,13 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (RCCL refuses two "
+                    "ranks on one device: use it with --backend gloo)")
+    ap.add_argument("--dist-always", action="store_true", help="initialise the process group, barrier and all-reduce "
+                    "even with one rank (exercises the RCCL leg on a one-GPU box)")
+    ap.add_argument("--min-seconds", type=float, default=0.0, help="repeat the K timed steps until the timed region "
+                    "lasts this long (reported steps = what ran); 0 = exactly --steps")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (single pair, host batch)")
     args = ap.parse_args()
 
     import torch
@@ -83,7 +162,8 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.dist_always
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -110,7 +190,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -119,17 +199,29 @@ def main():
     fence()
     eng.kernel_stats()  # clear
     eng.set_profiling(not args.no_events)
+    steps = args.steps
+    if args.min_seconds > 0:  # same count on every rank: estimated from rank 0's warm-up-sized probe
+        tp = time.perf_counter()
+        step()
+        fence()
+        est = torch.tensor([time.perf_counter() - tp], dtype=torch.float64,
+                           device="cuda" if (use_dist and args.backend == "nccl") else "cpu")
+        if use_dist:
+            dist.all_reduce(est, op=dist.ReduceOp.MAX)
+        steps = max(args.steps, int(args.min_seconds / max(float(est.item()), 1e-6)) + 1)
+        eng.kernel_stats()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
     stats = eng.kernel_stats()
     eng.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    args.steps = steps
 
     frames = world * B * args.steps
     fps = frames / dt
@@ -153,40 +245,56 @@ def main():
         "data": "synthetic",
         "config": {"workload": "KITTI-size %dx%d census/Hamming SGM, D=%d, %d paths, wsz=%d, P1=%d, P2=%d" %
                                (W, H, D, args.paths, args.wsz, args.p1, args.p2),
-                   "pairs_per_gpu_per_step": B, "sharding": "independent stereo pairs per rank, no data-path collective"},
+                   "pairs_per_gpu_per_step": B, "sharding": "independent stereo pairs per rank, no data-path collective",
+                   "dist_backend": (args.backend if use_dist else None)},
     }
 
     if rank == 0:
-        # Dominant kernel = the direction sweeps.  Algorithmic bytes of one launch (one direction over
-        # the launch group of B pairs) = B * V * (5N-2)/N on average over the N launches:
-        # the "materialised C + S volumes" model of SURVEY.md 8d.  The default engine path no longer moves
-        # those bytes (it recomputes C and stores one byte per voxel), so `traffic` -- HBM bytes per launch
-        # from the PMC passes in profiles/ -- is far below it and `frac` can exceed 1.
-        fast = args.p2 <= 255 and D <= 256
+        # Dominant kernel = the direction sweeps (8 launches per step).  `achieved` = the ALGORITHMIC bytes of
+        # one sweep launch in THIS engine's formulation / its average duration, measured live with
+        # HIP events on the launch stream: per pair one E byte per padded voxel written (h*w*Dp) + the two census
+        # images read once (h*w*4 + h*(w+Dp)*4) + the two border rings read and written (4 * (2w+2h)*Dp*2).
+        # The materialised formulation (--p2 > 255) moves SURVEY.md 8d's bytes: V*(5N-2)/N per launch and pair.
+        # SURVEY.md 8d's yardstick (materialised C + S volumes, 41 B/voxel) is kept as `model_bytes_equiv_GBs`:
+        # this engine never moves those bytes, so that figure is NOT a fraction of the HBM peak.
+        fast = args.p2 <= 255
         agg_ms, agg_n = stats["aggregate"]
         roof = None
         if agg_n:
-            per_launch_bytes = B * alg_agg / args.paths
+            h_, w_ = H - 2 * m, W - 2 * m
+            Dp = 32 * (1 if D <= 32 else 2 if D <= 64 else 4 if D <= 128 else 8 if D <= 256 else 12 if D <= 384 else 16)
+            model_bytes = B * alg_agg / args.paths
+            if fast:
+                launch_bytes = B * (h_ * w_ * Dp + h_ * w_ * 4 + h_ * (w_ + Dp) * 4 + 4 * (2 * w_ + 2 * h_) * Dp * 2)
+            else:
+                launch_bytes = model_bytes
             avg_s = agg_ms / agg_n * 1e-3
-            ach = per_launch_bytes / avg_s / 1e9
-            traffic = None
-            step_bytes = None
-            tfile = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
-            if fast and os.path.exists(tfile):
-                t = json.load(open(tfile))
-                cfg = t.get("config", {})
-                if cfg == {"batch": B, "width": W, "height": H, "disp": D, "paths": args.paths, "wsz": args.wsz}:
-                    traffic = t["kernels"]["aggregate3_kernel"]["hbm_bytes_per_launch"]
-                    k = t["kernels"]
-                    # HBM bytes of one whole step (PMC passes under profiles/): census + N sweeps + WTA + median
-                    step_bytes = (k["census4_kernel"]["hbm_bytes_per_launch"] + args.paths * traffic +
-                                  k["wta3_kernel"]["hbm_bytes_per_launch"] + k["median3_kernel"]["hbm_bytes_per_launch"])
+            ach = launch_bytes / avg_s / 1e9
+            cfg = {"batch": B, "width": W, "height": H, "disp": D, "paths": args.paths, "wsz": args.wsz}
+            t, tname = find_traffic(cfg) if fast else (None, None)
+            traffic = step_bytes = valu = None
+            if t:
+                k = t["kernels"]
+                traffic = k["aggregate3_kernel"]["hbm_bytes_per_launch"]
+                # HBM bytes of one whole step (PMC passes under profiles/): census + N sweeps + WTA + median
+                step_bytes = (k["census4_kernel"]["hbm_bytes_per_launch"] + args.paths * traffic +
+                              k["wta3_kernel"]["hbm_bytes_per_launch"] + k["median3_kernel"]["hbm_bytes_per_launch"])
+                sq = t.get("sq", {}).get("aggregate3_kernel")
+                if sq:
+                    # VALU issue: instructions per launch x measured cycles per instruction / (SIMDs x clock x time)
+                    nv, nx = sq["SQ_INSTS_VALU"], sq.get("xor_share", 0.0) * sq["SQ_INSTS_VALU"]
+                    cyc = (nv - nx) * VALU_CYCLES_SLOW + nx * VALU_CYCLES_FAST
+                    valu = {"insts_per_launch": nv, "cycles_per_inst_slow_fast": [VALU_CYCLES_SLOW, VALU_CYCLES_FAST],
+                            "fast_share": sq.get("xor_share", 0.0), "clock_GHz": sq.get("clock_GHz"),
+                            "frac": round(cyc / (N_SIMD * sq.get("clock_GHz", 2.2) * 1e9 * avg_s), 4)}
             roof = {"bound": "hbm", "kernel": "aggregate3_kernel" if fast else "aggregate_u16_kernel",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "avg_launch_ms": round(agg_ms / agg_n, 4),
-                    "alg_bytes_per_launch": per_launch_bytes,
+                    "traffic": traffic, "traffic_source": tname, "avg_launch_ms": round(agg_ms / agg_n, 4),
+                    "alg_bytes_per_launch": launch_bytes,
                     "hbm_GBs_from_traffic": round(traffic / avg_s / 1e9, 1) if traffic else None,
-                    "whole_pipeline_alg_GBs": round(alg_total * fps / world / 1e9, 1),
+                    "valu_issue": valu,
+                    "model_bytes_per_launch": model_bytes,
+                    "model_bytes_equiv_GBs": round(model_bytes / avg_s / 1e9, 1),
                     "step_hbm_bytes_from_pmc": step_bytes,
                     "step_hbm_GBs": round(step_bytes / (dt / args.steps) / 1e9, 1) if step_bytes else None,
                     "step_hbm_frac_of_peak": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if step_bytes else None,
@@ -222,9 +330,11 @@ def main():
                 cpu["independent_frames_on_all_cores"] = {"value": round(ncore / pdt, 4), "unit": "frames/s", "cores": ncore,
                                                           "sample": "%d frames, one per core" % ncore}
         out["cpu_baseline"] = cpu
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_figures(eng, sv, args, Lh, Rh, B, W, H)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

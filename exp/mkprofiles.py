@@ -3,6 +3,7 @@
 <TAG>_bench_under_rocprof.json."""
 import csv, glob, json, os, sys, collections, shutil
 tag = sys.argv[1]
+XOR_SHARE = float(os.environ.get("SGMX_XOR_SHARE", "0.17"))  # v_xor_b32 share of the sweep's VALU instructions (exp/step_mix.py)
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "gpurun_out", "prof_" + tag, "summary")
@@ -38,6 +39,33 @@ for k, d in per.items():
     f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
     out["kernels"][k] = {"launches_averaged": n, "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                          "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+# SQ / GRBM passes (optional): per-launch averages for the sweep kernel
+sq = {}
+for sub in ("sq", "grbm"):
+    fs = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
+    if not fs:
+        continue
+    acc = collections.defaultdict(list)
+    dur = []
+    for r in csv.DictReader(open(fs[0])):
+        if "aggregate3_kernel" not in r["Kernel_Name"]:
+            continue
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if sub == "grbm":
+            dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in acc.items():
+        sq[k] = sum(v) / len(v)
+    if sub == "grbm" and dur and "GRBM_GUI_ACTIVE" in sq:
+        # the counter sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+        sq["clock_GHz"] = round(sq["GRBM_GUI_ACTIVE"] / 8 / (sum(dur) / len(dur)), 3)
+        sq["duration_ns_under_pmc"] = sum(dur) / len(dur)
+if sq:
+    sq["xor_share"] = XOR_SHARE
+    out["sq"] = {"aggregate3_kernel": sq}
+sys.path.insert(0, root)
+import bench
+out["kernel_src_sha256"] = bench.kernel_src_sha256()
+out["git_head"] = os.environ.get("GIT_HEAD", "unknown")
 json.dump(out, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read())
 print(json.dumps(out["kernels"], indent=1))

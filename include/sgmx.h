@@ -15,7 +15,10 @@
  *  - "host" entry points take host pointers and are synchronous.
  *  - "_dev" entry points take device pointers (hipMalloc'd memory on the
  *    context's device) plus a hipStream_t passed as void*; they only enqueue
- *    work on that stream and return; the caller synchronises.
+ *    work on that stream and return; the caller synchronises.  Calls on one
+ *    context share its scratch: a call on another stream than the previous one
+ *    first waits (on the device) for that call's last launch group, so calls
+ *    through one context never overlap; use one context per concurrent stream.
  *  - a context owns all device scratch and is reused across calls; one context
  *    per (host thread, device).  Nothing is written to the file system.
  *  - volumes are [y][x][d] with d fastest; images are row-major.
@@ -55,11 +58,12 @@ typedef struct sgmx_params {
                         the reference's x86-64 builds do (stereo_sgm.h:309,312)      */
     int window_sz;   /* census window, odd, 1..31 (an even window reads past the image in the reference); m = (wsz-1)/2; ignored by the float path */
     int penalty1;    /* P1 >= 0                                                                 */
-    int penalty2;    /* P2 >= 0; 36*255 + 8*P2 and P1 + 9*255 + P2 must stay below the uint16 guards */
+    int penalty2;    /* P2 >= 0.  Census entry points: 36*255 + 8*P2 and P1 + 9*255 + P2 must stay below the
+                        uint16 guards (SGMX_ERR_RANGE from the call otherwise); the float pipelines take any */
     int num_paths;   /* 8 (default; order of stereo_sgm.cc:120-122) or 4 (its axis-aligned subset) */
     int device;      /* HIP device ordinal (default 0)                                           */
     int max_batch;   /* stereo pairs processed per launch group (default 1); sizes the scratch   */
-    int flags;       /* 0, or SGMX_FLAG_MATERIALIZE / SGMX_FLAG_NO_SMALL_GROUPS                   */
+    int flags;       /* 0 or SGMX_FLAG_MATERIALIZE                                                */
 } sgmx_params;
 
 /* flags: keep the data-cost volume C and the summed-cost volume S in HBM as the reference does
@@ -67,9 +71,6 @@ typedef struct sgmx_params {
  * census path recomputes C from the census images and stores one byte per voxel and direction
  * instead; the results are identical.  penalty2 > 255 always uses the materialised form. */
 #define SGMX_FLAG_MATERIALIZE 1
-/* flags: accepted, no effect.  (Earlier builds ran launch groups of a few pairs on the materialised
- * kernels and this flag switched that off; the volume-free kernels are now faster at every size.) */
-#define SGMX_FLAG_NO_SMALL_GROUPS 2
 
 typedef struct sgmx_ctx sgmx_ctx;
 
@@ -210,6 +211,37 @@ SGMX_API int sgmx_match_hamming_thres_prealloc(sgmx_ctx *ctx, const uint8_t *bs1
                                                int ncodes, int *idx, uint16_t *hams, size_t capacity, size_t *nptr);
 SGMX_API int sgmx_crossmatch_hamming_prealloc(sgmx_ctx *ctx, const uint8_t *dbs, long n, int ht, int ncodes, int *idx,
                                               uint16_t *hams, size_t capacity, size_t *nptr);
+
+/* The allocating and "threaded" forms of the same library (core/hamming.h:84-96, 108-112).
+ *   sgmx_hammatch                   hammatch_t                  core/hamming.h:52-56 (same layout: two ints, a uint16)
+ *   sgmx_match_hamming_thres        match_hamming_thres         core/hamming.h:84-86, core/hamming.c:533-577
+ *   sgmx_crossmatch_hamming         crossmatch_hamming          core/hamming.h:95-96, core/hamming.c:768-807
+ *     *hmptr receives a malloc'ed array of at least max(bufsize, 1) records (the reference mallocs bufsize and grows
+ *     it by realloc), *nptr the number of matches, records in the reference's loop order; release with
+ *     sgmx_free (= free()).  On an error return *hmptr is still a valid malloc'ed (or NULL) pointer to release.
+ *   sgmx_compute_hamming_thread     compute_hamming_thread      core/hamming.h:108-109, core/hamming.c:849-860
+ *     the same matrix as compute_hamming.
+ *   sgmx_match_hamming_thres_nt     match_hamming_thres_nt      core/hamming.h:111-112, core/hamming.c:863-919
+ *     The reference cuts both sets into blocks of 128 signatures and writes block pair by block pair: matches are
+ *     ordered by block pair (bl = 0 .. nblock1*nblock2-1; queries of block bl / nblock1, base block bl % nblock1),
+ *     then query, then base, and the stored indices are LOCAL to the block pair (0..127) -- reproduced as is.  Its
+ *     block arithmetic stays inside the sets only when both sets have the same number of blocks; other shapes are
+ *     SGMX_ERR_INVALID_ARG here (undefined behaviour there).  nt is accepted and ignored.  *keys (2 ints per match)
+ *     and *ham are malloc'ed; the reference returns the count, here it goes to *nmatches.  Release with sgmx_free. */
+typedef struct sgmx_hammatch {
+    int qid;        /* query id */
+    int bid;        /* base id */
+    uint16_t score; /* Hamming distance */
+} sgmx_hammatch;
+SGMX_API int sgmx_match_hamming_thres(sgmx_ctx *ctx, const uint8_t *bs1, const uint8_t *bs2, int n1, int n2, int ht, int ncodes,
+                                      size_t bufsize, sgmx_hammatch **hmptr, size_t *nptr);
+SGMX_API int sgmx_crossmatch_hamming(sgmx_ctx *ctx, const uint8_t *dbs, long n, int ht, int ncodes, long bufsize,
+                                     sgmx_hammatch **hmptr, size_t *nptr);
+SGMX_API int sgmx_compute_hamming_thread(sgmx_ctx *ctx, uint16_t *dis, const uint8_t *a, const uint8_t *b, int na, int nb,
+                                         int ncodes);
+SGMX_API int sgmx_match_hamming_thres_nt(sgmx_ctx *ctx, const uint8_t *bs1, const uint8_t *bs2, int n1, int n2, int ht,
+                                         int ncodes, int nt, int **keys, uint16_t **ham, size_t *nmatches);
+SGMX_API void sgmx_free(void *ptr);
 
 /* After a compute call, copy stages of pair `index` (0-based within the last
  * launch group) to the host: the data cost C [h][w][D] (uint8 for the census

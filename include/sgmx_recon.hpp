@@ -334,6 +334,10 @@ class SGMStereo {
         if (P1 >= P2)
             throw std::invalid_argument("[SGMStereo::SetSmoothnessCostParameters] small value of smoothness penalty must be "
                                         "smaller than large penalty value");
+        // the reference keeps them as float (sgm_stereo.h:63-64); sgmx_params holds ints, so fractional
+        // penalties are refused instead of truncated
+        if (P1 != (double)(int)P1 || P2 != (double)(int)P2)
+            throw std::invalid_argument("[SGMStereo::SetSmoothnessCostParameters] this engine takes whole-number penalties");
         P1_ = (int)P1;
         P2_ = (int)P2;
     }

@@ -175,6 +175,95 @@ def ref_match_hamming(bs1, bs2, ht, cross=False):
     return idx, hams
 
 
+class _HamMatch(C.Structure):  # hammatch_t, core/hamming.h:52-56
+    _fields_ = [("qid", C.c_int), ("bid", C.c_int), ("score", C.c_uint16)]
+
+
+def _libc_free(ptr):
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(ptr)
+
+
+def ref_match_hamming_alloc(bs1, bs2, ht, cross=False, bufsize=16):
+    """The reference's own allocating forms (oracle/_ref): match_hamming_thres / crossmatch_hamming
+    (core/hamming.c:533-577, 768-807) -> idx (n, 2), scores (n,).  None when that build is absent."""
+    if not os.path.exists(_REF_HAMMING):
+        return None
+    L = C.CDLL(_REF_HAMMING)
+    a = np.ascontiguousarray(bs1, np.uint8)
+    hm, n = C.POINTER(_HamMatch)(), C.c_size_t(0)
+    if cross:
+        L.crossmatch_hamming.argtypes = [u8p, C.c_long, C.c_int, C.c_int, C.c_long, C.POINTER(C.POINTER(_HamMatch)), C.POINTER(C.c_size_t)]
+        L.crossmatch_hamming.restype = None
+        L.crossmatch_hamming(a, a.shape[0], ht, a.shape[1], bufsize, C.byref(hm), C.byref(n))
+    else:
+        b = np.ascontiguousarray(bs2, np.uint8)
+        L.match_hamming_thres.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                          C.POINTER(C.POINTER(_HamMatch)), C.POINTER(C.c_size_t)]
+        L.match_hamming_thres.restype = None
+        L.match_hamming_thres(a, b, a.shape[0], b.shape[0], ht, a.shape[1], bufsize, C.byref(hm), C.byref(n))
+    idx = np.array([(hm[i].qid, hm[i].bid) for i in range(n.value)], np.int32).reshape(-1, 2)
+    sc = np.array([hm[i].score for i in range(n.value)], np.uint16)
+    _libc_free(C.cast(hm, C.c_void_p))
+    return idx, sc
+
+
+def ref_hamming_matrix_thread(a, b):
+    """The reference's compute_hamming_thread (core/hamming.c:849-860; OpenMP build of oracle/_ref)."""
+    if not os.path.exists(_REF_HAMMING):
+        return None
+    L = C.CDLL(_REF_HAMMING)
+    if not hasattr(L, "compute_hamming_thread"):
+        return None
+    L.compute_hamming_thread.argtypes = [u16p, u8p, u8p, C.c_int, C.c_int, C.c_int]
+    L.compute_hamming_thread.restype = None
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.empty((b.shape[0], a.shape[0]), np.uint16)
+    L.compute_hamming_thread(out, a, b, a.shape[0], b.shape[0], a.shape[1])
+    return out
+
+
+def ref_match_hamming_thres_nt(bs1, bs2, ht, nt=4):
+    """The reference's match_hamming_thres_nt (core/hamming.c:863-919): keys (n, 2) block-local, distances (n,).
+    Only defined when both sets have the same number of 128-blocks (its block arithmetic leaves the sets otherwise)."""
+    if not os.path.exists(_REF_HAMMING):
+        return None
+    L = C.CDLL(_REF_HAMMING)
+    if not hasattr(L, "match_hamming_thres_nt"):
+        return None
+    a = np.ascontiguousarray(bs1, np.uint8)
+    b = np.ascontiguousarray(bs2, np.uint8)
+    assert (a.shape[0] - 1) // 128 == (b.shape[0] - 1) // 128
+    keys, ham = C.POINTER(C.c_int)(), C.POINTER(C.c_uint16)()
+    L.match_hamming_thres_nt.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_uint16))]
+    L.match_hamming_thres_nt.restype = C.c_size_t
+    n = L.match_hamming_thres_nt(a, b, a.shape[0], b.shape[0], ht, a.shape[1], nt, C.byref(keys), C.byref(ham))
+    k = np.array([keys[i] for i in range(2 * n)], np.int32).reshape(-1, 2)
+    h = np.array([ham[i] for i in range(n)], np.uint16)
+    _libc_free(C.cast(keys, C.c_void_p))
+    _libc_free(C.cast(ham, C.c_void_p))
+    return k, h
+
+
+def match_hamming_blocked(bs1, bs2, ht):
+    """Restatement of match_hamming_thres_nt's output order on top of match_hamming (numpy): block pairs of 128 x 128
+    in the order of core/hamming.c:875-880, block-local indices."""
+    a = np.ascontiguousarray(bs1, np.uint8)
+    b = np.ascontiguousarray(bs2, np.uint8)
+    nb1, nb2 = 1 + (a.shape[0] - 1) // 128, 1 + (b.shape[0] - 1) // 128
+    assert nb1 == nb2
+    ks, hs = [], []
+    for bl in range(nb1 * nb2):
+        s1, s2 = (bl // nb1) * 128, (bl % nb1) * 128
+        k, h = match_hamming(a[s1:s1 + 128], b[s2:s2 + 128], ht)
+        ks.append(k)
+        hs.append(h)
+    return np.concatenate(ks).reshape(-1, 2), np.concatenate(hs)
+
+
 def aggregate_dir_u32(Cvol, dx, dy, P1, P2, buf, edges=False):
     h, w, D = Cvol.shape
     fn = lib().oracle_aggregate_dir_u32_edges if edges else lib().oracle_aggregate_dir_u32

@@ -5,4 +5,4 @@ and C ABI (csrc/, include/sgmx.h -> libsgmx.so) and the host-side mirror of
 recon::StereoSGM / recon::SGM (sgm.py)."""
 from .sgm import (SGM, SGMParams, SGMStereo, StereoSGM, StereoSGMParams, load_data_cost, load_representation,  # noqa: F401
                   save_representation)
-from ._lib import FLAG_MATERIALIZE, FLAG_NO_SMALL_GROUPS, SgmxError  # noqa: F401
+from ._lib import FLAG_MATERIALIZE, SgmxError  # noqa: F401

@@ -9,7 +9,6 @@ LIB_PATH = os.environ.get("SGMX_LIB") or os.path.join(_HERE, "libsgmx.so")  # SG
 
 SGMX_OK = 0
 FLAG_MATERIALIZE = 1  # SGMX_FLAG_MATERIALIZE
-FLAG_NO_SMALL_GROUPS = 2  # SGMX_FLAG_NO_SMALL_GROUPS
 ERR_NAMES = {1: "INVALID_ARG", 2: "RANGE", 3: "NO_DEVICE", 4: "HIP", 5: "OOM", 6: "STATE"}
 K_CENSUS, K_HAMMING, K_AGGREGATE, K_WTA, K_MEDIAN, K_COUNT = range(6)
 KERNEL_CLASS_NAMES = ["census", "hamming_volume", "aggregate", "wta", "median"]
@@ -49,6 +48,11 @@ SYMBOLS = {
     "sgmx_crossmatch_hamming_count": (_i, [_vp, _vp, C.c_long, _i, _i, C.POINTER(C.c_size_t)]),
     "sgmx_match_hamming_thres_prealloc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sgmx_crossmatch_hamming_prealloc": (_i, [_vp, _vp, C.c_long, _i, _i, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sgmx_match_hamming_thres": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_size_t, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "sgmx_crossmatch_hamming": (_i, [_vp, _vp, C.c_long, _i, _i, C.c_long, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "sgmx_compute_hamming_thread": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
+    "sgmx_match_hamming_thres_nt": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "sgmx_free": (None, [_vp]),
     "sgmx_get_stages_census": (_i, [_vp, _i, _vp, _vp, _vp]),
     "sgmx_get_stages_f32": (_i, [_vp, _i, _vp, _vp]),
     "sgmx_get_data_cost_wta_u8": (_i, [_vp, _i, _vp]),

@@ -10,7 +10,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -32,6 +34,19 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 
+// Device buffers and geometry of one census launch group in the volume-free formulation.  The context's own
+// scratch is one such view (ensure_scratch); sgmx_compute_census_u8_dev_noalloc builds another over the static
+// array below.
+struct FastView {
+    int W = 0, H = 0, w = 0, h = 0, m = 0, wp = 0;
+    int cap = 0;                 // pairs the view holds (the E volumes of two directions lie cap pairs apart)
+    size_t bytes_E = 0;          // one pair of one direction
+    size_t bytes_BL = 0;         // one pair's border ring
+    u32 *cl = nullptr, *cr = nullptr;
+    uint8_t *E = nullptr;
+    uint16_t *BL = nullptr, *SB = nullptr, *raw = nullptr;
+};
+
 } // namespace
 
 struct sgmx_ctx {
@@ -47,12 +62,12 @@ struct sgmx_ctx {
     bool fast = false;         // census path without C / S volumes (sgmx_kernels_v2.hpp): P2 <= 255
     int RP = 4, DpF = 128;     // fast path: packed pairs per lane, padded disparity count 32 * RP
     int wp = 0;                // row pitch of the padded right census image (fast path)
-    int small_n = 0;           // fast contexts: launch groups of <= small_n pairs take the materialised kernels
-    bool last_fast = false;    // formulation the last census launch group used (for the taps)
-    u32 *d_cr_dense = nullptr; // dense right census for the materialised kernels (== d_cr in non-fast contexts)
-    void *d_BLm = nullptr;     // border ring of the materialised kernels (== d_BL in non-fast contexts)
-    size_t bytes_BLm = 0;
     int last_n = 0;            // pairs in the last launch group
+    // The scratch below is shared by every call on this context.  ev_scratch is recorded behind the last
+    // launch group; a call on another stream waits for it before it touches the scratch.
+    hipEvent_t ev_scratch = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
 
     // device scratch (sized for max_batch pairs)
     uint8_t *d_left = nullptr, *d_right = nullptr; // staged inputs for the host entry points
@@ -109,12 +124,6 @@ void free_scratch(sgmx_ctx *c)
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
-    if (c->d_cr_dense && c->d_cr_dense != c->d_cr)
-        (void)hipFree(c->d_cr_dense);
-    if (c->d_BLm && c->d_BLm != c->d_BL)
-        (void)hipFree(c->d_BLm);
-    c->d_cr_dense = nullptr;
-    c->d_BLm = nullptr;
     c->d_left = c->d_right = nullptr;
     c->d_left2 = c->d_right2 = nullptr;
     c->d_out2 = nullptr;
@@ -130,11 +139,31 @@ void free_scratch(sgmx_ctx *c)
     c->W = c->H = 0;
 }
 
-// (Re)allocate scratch for `mode` at image/volume size W x H.
-int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
+// Order the scratch between streams: a call on a stream other than the last user's waits for that user's
+// last launch group (sgmx.h: "_dev" entry points).
+int scratch_acquire(sgmx_ctx *c, hipStream_t st)
+{
+    if (c->scratch_used && st != c->scratch_stream)
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_scratch, 0));
+    return SGMX_OK;
+}
+int scratch_release(sgmx_ctx *c, hipStream_t st)
+{
+    HIPCHK(c, hipEventRecord(c->ev_scratch, st));
+    c->scratch_stream = st;
+    c->scratch_used = true;
+    return SGMX_OK;
+}
+
+// (Re)allocate scratch for `mode` at image/volume size W x H; `st` is the stream of the call that needs it
+// (the buffers' initial memsets are ordered on it).
+int ensure_scratch(sgmx_ctx *c, int mode, int W, int H, hipStream_t st)
 {
     if (c->mode == mode && c->W == W && c->H == H)
-        return SGMX_OK;
+        return scratch_acquire(c, st);
+    if (c->scratch_used) // the previous geometry's buffers may still be in use on another stream
+        HIPCHK(c, hipEventSynchronize(c->ev_scratch));
+    c->scratch_used = false;
     free_scratch(c);
     const int B = c->prm.max_batch;
     const int m = mode == 1 ? (c->prm.window_sz - 1) / 2 : 0;
@@ -143,7 +172,7 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
     const size_t esz_c = mode == 1 ? 1 : 4, esz_s = mode == 1 ? 2 : 4;
     c->bytes_C = npix * c->Dp * esz_c;
     c->bytes_S = npix * c->Dp * esz_s;
-    c->bytes_BL = c->bytes_BLm = (size_t)(2 * w + 2 * h) * c->Dp * esz_s;
+    c->bytes_BL = (size_t)(2 * w + 2 * h) * c->Dp * esz_s;
     if (mode == 1 && c->fast)
         c->bytes_BL = (size_t)(2 * w + 2 * h) * c->DpF * 2;
     const bool fast = mode == 1 && c->fast;
@@ -156,26 +185,16 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
         HIPCHK(c, hipMalloc((void **)&c->d_out2, nfull * 2 * B));
         HIPCHK(c, hipMalloc((void **)&c->d_cl, npix * 4 * B));
         HIPCHK(c, hipMalloc((void **)&c->d_cr, (size_t)c->wp * h * 4 * B));
-        HIPCHK(c, hipMemset(c->d_cr, 0, (size_t)c->wp * h * 4 * B)); // the padding columns are never written again
+        HIPCHK(c, hipMemsetAsync(c->d_cr, 0, (size_t)c->wp * h * 4 * B, st)); // the padding columns are never written again
     }
     HIPCHK(c, hipMalloc(&c->d_BL, c->bytes_BL * B));
     if (fast) {
         c->bytes_E = npix * c->DpF;
         HIPCHK(c, hipMalloc((void **)&c->d_E, c->bytes_E * B * c->prm.num_paths));
         HIPCHK(c, hipMalloc((void **)&c->d_SB, c->bytes_BL * B));
-        // small launch groups are latency-bound and run faster on the one-path-per-wave kernels
-        const int ns = c->small_n < B ? c->small_n : B;
-        if (ns > 0) {
-            HIPCHK(c, hipMalloc(&c->d_C, c->bytes_C * ns));
-            HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * ns));
-            HIPCHK(c, hipMalloc(&c->d_BLm, c->bytes_BLm * ns));
-            HIPCHK(c, hipMalloc((void **)&c->d_cr_dense, npix * 4 * ns));
-        }
     } else {
         HIPCHK(c, hipMalloc(&c->d_C, c->bytes_C * B));
         HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * B));
-        c->d_BLm = c->d_BL;
-        c->d_cr_dense = c->d_cr;
     }
     if (mode == 3) {
         HIPCHK(c, hipMalloc((void **)&c->d_C2, c->bytes_C * B));
@@ -190,7 +209,7 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H)
     HIPCHK(c, hipMalloc((void **)&c->d_out, nfull * 2 * B));
     // the zero border of the disparity image (stereo_sgm.h:280) is written once here;
     // the WTA kernel only ever touches the interior
-    HIPCHK(c, hipMemset(c->d_raw, 0, nfull * 2 * B));
+    HIPCHK(c, hipMemsetAsync(c->d_raw, 0, nfull * 2 * B, st));
     c->mode = mode;
     c->W = W;
     c->H = H;
@@ -265,14 +284,14 @@ template <bool F32> void launch_agg(int R, bool first, bool pad, const AggArgs &
 int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st, const void *Cvol, const int (*order)[2] = nullptr)
 {
     const int np = order ? 8 : c->prm.num_paths;
-    HIPCHK(c, hipMemsetAsync(c->d_BLm, 0, c->bytes_BLm * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
+    HIPCHK(c, hipMemsetAsync(c->d_BL, 0, c->bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
     for (int k = 0; k < np; k++) {
         if (order && k > 0)
-            HIPCHK(c, hipMemsetAsync(c->d_BLm, 0, c->bytes_BLm * n, st));
+            HIPCHK(c, hipMemsetAsync(c->d_BL, 0, c->bytes_BL * n, st));
         AggArgs a;
         a.C = Cvol;
         a.S = c->d_S;
-        a.BL = c->d_BLm;
+        a.BL = c->d_BL;
         a.w = c->w;
         a.h = c->h;
         a.D = c->prm.disp_range;
@@ -301,6 +320,10 @@ int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t s
         const dim3 grid(c->h, n);
         if (!f32) {
             const size_t lds = (size_t)c->w * 8;
+            if (lds > 64 * 1024) {
+                const void *fn = c->R == 1 ? (const void *)wta_u16_kernel<1> : (c->R == 2 ? (const void *)wta_u16_kernel<2> : (const void *)wta_u16_kernel<4>);
+                HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
             if (c->R == 1)
                 hipLaunchKernelGGL(wta_u16_kernel<1>, grid, dim3(256), lds, st, (const uint16_t *)c->d_S, c->w, c->h, c->prm.disp_range, c->m, c->d_raw);
             else if (c->R == 2)
@@ -309,6 +332,10 @@ int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t s
                 hipLaunchKernelGGL(wta_u16_kernel<4>, grid, dim3(256), lds, st, (const uint16_t *)c->d_S, c->w, c->h, c->prm.disp_range, c->m, c->d_raw);
         } else {
             const size_t lds = (size_t)c->w * 16;
+            if (lds > 64 * 1024) {
+                const void *fn = c->R == 1 ? (const void *)wta_f32_kernel<1> : (c->R == 2 ? (const void *)wta_f32_kernel<2> : (const void *)wta_f32_kernel<4>);
+                HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
             if (c->R == 1)
                 hipLaunchKernelGGL(wta_f32_kernel<1>, grid, dim3(256), lds, st, (const float *)c->d_S, c->w, c->h, c->prm.disp_range, c->d_raw);
             else if (c->R == 2)
@@ -349,66 +376,88 @@ template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t 
     }
 }
 
-SumArgs sum_args(const sgmx_ctx *c)
+SumArgs sum_args(const sgmx_ctx *c, const FastView &v)
 {
     SumArgs a;
-    a.cl = c->d_cl;
-    a.cr = c->d_cr;
-    a.E = c->d_E;
-    a.estride = c->bytes_E * c->prm.max_batch;
-    a.SB = c->d_SB;
-    a.w = c->w;
-    a.h = c->h;
+    a.cl = v.cl;
+    a.cr = v.cr;
+    a.E = v.E;
+    a.estride = v.bytes_E * v.cap;
+    a.SB = v.SB;
+    a.w = v.w;
+    a.h = v.h;
     a.D = c->prm.disp_range;
-    a.wp = c->wp;
+    a.wp = v.wp;
     a.N = c->prm.num_paths;
     return a;
 }
 
-size_t wta3_lds_bytes(const sgmx_ctx *c) { return (size_t)16 * (c->DpF / 2) * 4 + (size_t)c->w * 16; }
+size_t wta3_lds_bytes(int DpF, int w) { return (size_t)16 * (DpF / 2) * 4 + (size_t)w * 16; }
+
+// The context's own scratch as a view (valid after ensure_scratch(mode 1) on a fast context).
+FastView ctx_view(const sgmx_ctx *c)
+{
+    FastView v;
+    v.W = c->W; v.H = c->H; v.w = c->w; v.h = c->h; v.m = c->m; v.wp = c->wp;
+    v.cap = c->prm.max_batch;
+    v.bytes_E = c->bytes_E;
+    v.bytes_BL = c->bytes_BL;
+    v.cl = c->d_cl; v.cr = c->d_cr; v.E = c->d_E;
+    v.BL = (uint16_t *)c->d_BL; v.SB = c->d_SB; v.raw = c->d_raw;
+    return v;
+}
 
 // Fast census path: the ordered direction sweeps writing byte volumes, then the fused
-// sum + WTA / LR / subpixel kernel and the median.
-int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
+// sum + WTA / LR / subpixel kernel and the median.  prof == false: no event is created (the entry point
+// that allocates nothing).
+int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_t st, bool prof)
 {
     const int np = c->prm.num_paths;
-    HIPCHK(c, hipMemsetAsync(c->d_BL, 0, c->bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
-    HIPCHK(c, hipMemsetAsync(c->d_SB, 0, c->bytes_BL * n, st));
+    const bool was_profiling = c->profiling;
+    if (!prof)
+        c->profiling = false;
+    struct Restore {
+        sgmx_ctx *c;
+        bool v;
+        ~Restore() { c->profiling = v; }
+    } restore{c, was_profiling};
+    HIPCHK(c, hipMemsetAsync(v.BL, 0, v.bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
+    HIPCHK(c, hipMemsetAsync(v.SB, 0, v.bytes_BL * n, st));
     const bool pad = c->prm.disp_range != c->DpF;
     for (int k = 0; k < np; k++) {
         Agg2Args a;
-        a.w = c->w;
-        a.h = c->h;
+        a.w = v.w;
+        a.h = v.h;
         a.D = c->prm.disp_range;
-        a.wp = c->wp;
+        a.wp = v.wp;
         a.dx = np == 8 ? DIRS8[k][0] : DIRS4[k][0];
         a.dy = np == 8 ? DIRS8[k][1] : DIRS4[k][1];
         a.P1 = c->prm.penalty1;
         a.P2 = c->prm.penalty2;
-        a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
+        a.npaths = a.dy == 0 ? v.h : (a.dx == 0 ? v.w : v.w + v.h - 1);
         a.npairs = n;
         const dim3 grid(8 * ((((a.npaths + 15) / 16) * n + 7) / 8)); // 4 waves x 4 paths per workgroup, 8 equal XCD chunks
-        uint8_t *Ek = c->d_E + (size_t)k * c->bytes_E * c->prm.max_batch;
+        uint8_t *Ek = v.E + (size_t)k * v.bytes_E * v.cap;
         ProfScope ps(c, SGMX_K_AGGREGATE, st);
         if (c->RP == 1)
-            launch_agg3<1>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<1>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
         else if (c->RP == 2)
-            launch_agg3<2>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<2>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
         else if (c->RP == 4)
-            launch_agg3<4>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<4>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
         else if (c->RP == 8)
-            launch_agg3<8>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<8>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
         else if (c->RP == 12)
-            launch_agg3<12>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<12>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
         else
-            launch_agg3<16>(k == 0, pad, grid, st, c->d_cl, c->d_cr, Ek, (uint16_t *)c->d_BL, c->d_SB, a);
+            launch_agg3<16>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
         HIPCHK(c, hipGetLastError());
     }
     {
         ProfScope ps(c, SGMX_K_WTA, st);
-        const SumArgs sa = sum_args(c);
-        const size_t lds = wta3_lds_bytes(c);
-        const dim3 grid(c->h, n);
+        const SumArgs sa = sum_args(c, v);
+        const size_t lds = wta3_lds_bytes(c->DpF, v.w);
+        const dim3 grid(v.h, n);
         const bool wpad = c->prm.disp_range != c->DpF;
         const int P2 = c->prm.penalty2;
 #define SGMX_WTA(RPV)                                                                                                  \
@@ -417,12 +466,12 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
             if (lds > 64 * 1024)                                                                                       \
                 HIPCHK(c, hipFuncSetAttribute((const void *)wta3_kernel<RPV, true>,                                    \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            hipLaunchKernelGGL((wta3_kernel<RPV, true>), grid, dim3(256), lds, st, sa, P2, c->m, c->d_raw);             \
+            hipLaunchKernelGGL((wta3_kernel<RPV, true>), grid, dim3(256), lds, st, sa, P2, v.m, v.raw);                 \
         } else {                                                                                                       \
             if (lds > 64 * 1024)                                                                                       \
                 HIPCHK(c, hipFuncSetAttribute((const void *)wta3_kernel<RPV, false>,                                   \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            hipLaunchKernelGGL((wta3_kernel<RPV, false>), grid, dim3(256), lds, st, sa, P2, c->m, c->d_raw);            \
+            hipLaunchKernelGGL((wta3_kernel<RPV, false>), grid, dim3(256), lds, st, sa, P2, v.m, v.raw);                \
         }                                                                                                              \
     } while (0)
         if (c->RP == 1)
@@ -442,7 +491,7 @@ int run_fast(sgmx_ctx *c, int n, uint16_t *d_disp, hipStream_t st)
     }
     {
         ProfScope ps(c, SGMX_K_MEDIAN, st);
-        hipLaunchKernelGGL(median3_kernel, dim3((c->W + 255) / 256, c->H, n), dim3(256), 0, st, c->d_raw, c->W, c->H, d_disp);
+        hipLaunchKernelGGL(median3_kernel, dim3((v.W + 255) / 256, v.H, n), dim3(256), 0, st, v.raw, v.W, v.H, d_disp);
         HIPCHK(c, hipGetLastError());
     }
     return SGMX_OK;
@@ -461,46 +510,57 @@ int materialize_cost(sgmx_ctx *c, int index, uint8_t *d_dst, hipStream_t st)
     return SGMX_OK;
 }
 
-// One launch group (n <= max_batch) of the census path, everything device resident.
+// Census transform of n pairs into the census images at cl / cr (right image: row pitch `pitch`, pixel x in
+// column xoff + x).
+int run_census(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, int W, int H, u32 *cl, u32 *cr, int pitch, int xoff,
+               hipStream_t st, bool prof)
+{
+    const int m = (c->prm.window_sz - 1) / 2, w = W - 2 * m, h = H - 2 * m;
+    const bool was_profiling = c->profiling;
+    if (!prof)
+        c->profiling = false;
+    {
+        ProfScope ps(c, SGMX_K_CENSUS, st);
+        const dim3 g4((w + 1023) / 1024, h, 2 * n);
+        if (c->prm.window_sz == 5 && W >= 8)
+            hipLaunchKernelGGL(census4_kernel<5>, g4, dim3(256), 0, st, dL, dR, n, W, H, cl, cr, pitch, xoff);
+        else if (c->prm.window_sz == 3 && W >= 8)
+            hipLaunchKernelGGL(census4_kernel<3>, g4, dim3(256), 0, st, dL, dR, n, W, H, cl, cr, pitch, xoff);
+        else
+            hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 2 * n), dim3(256), 0, st, dL, dR, n, W, H,
+                               c->prm.window_sz, cl, cr, pitch, xoff);
+    }
+    c->profiling = was_profiling;
+    HIPCHK(c, hipGetLastError());
+    return SGMX_OK;
+}
+
+// One launch group (n <= max_batch) of the census path on the context's scratch, everything device resident.
+// Both formulations give the same bits; contexts with P2 <= 255 run the volume-free one (sgmx_kernels_v2.hpp),
+// the faster one at every group size measured.
 int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint16_t *d_disp, hipStream_t st)
 {
     const int W = c->W, H = c->H, w = c->w, h = c->h;
-    // Both formulations give the same bits.  The fast one (4 paths per wave, no volumes) wins once the
-    // launch group fills the chip; a group of a few pairs is latency-bound and runs faster on the
-    // one-path-per-wave kernels with the C / S volumes (they then sit in the Infinity Cache anyway).
-    const bool use_fast = c->fast && n > c->small_n;
-    c->last_fast = use_fast;
-    {
-        ProfScope ps(c, SGMX_K_CENSUS, st);
-        u32 *cr = use_fast ? c->d_cr : c->d_cr_dense;
-        const int pitch = use_fast ? c->wp : w, xoff = use_fast ? c->DpF : 0;
-        const dim3 g4((w + 1023) / 1024, h, 2 * n);
-        if (c->prm.window_sz == 5 && W >= 8)
-            hipLaunchKernelGGL(census4_kernel<5>, g4, dim3(256), 0, st, dL, dR, n, W, H, c->d_cl, cr, pitch, xoff);
-        else if (c->prm.window_sz == 3 && W >= 8)
-            hipLaunchKernelGGL(census4_kernel<3>, g4, dim3(256), 0, st, dL, dR, n, W, H, c->d_cl, cr, pitch, xoff);
-        else
-            hipLaunchKernelGGL(census_kernel, dim3((w + 255) / 256, h, 2 * n), dim3(256), 0, st, dL, dR, n, W, H,
-                               c->prm.window_sz, c->d_cl, cr, pitch, xoff);
-        HIPCHK(c, hipGetLastError());
-    }
-    if (use_fast) {
-        const int rc = run_fast(c, n, d_disp, st);
-        c->last_n = n;
-        return rc;
-    }
-    {
-        ProfScope ps(c, SGMX_K_HAMMING, st);
-        const size_t groups = (size_t)n * w * h * (c->Dp / 16);
-        hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, c->d_cl,
-                           c->d_cr_dense, w, 0, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
-        HIPCHK(c, hipGetLastError());
-    }
-    int rc = run_aggregation(c, n, false, st, c->d_C);
+    int rc = run_census(c, n, dL, dR, W, H, c->d_cl, c->d_cr, c->fast ? c->wp : w, c->fast ? c->DpF : 0, st, true);
     if (rc)
         return rc;
-    rc = run_wta_median(c, n, false, d_disp, st);
+    if (c->fast) {
+        rc = run_fast(c, ctx_view(c), n, d_disp, st, true);
+    } else {
+        {
+            ProfScope ps(c, SGMX_K_HAMMING, st);
+            const size_t groups = (size_t)n * w * h * (c->Dp / 16);
+            hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, c->d_cl,
+                               c->d_cr, w, 0, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
+            HIPCHK(c, hipGetLastError());
+        }
+        rc = run_aggregation(c, n, false, st, c->d_C);
+        if (!rc)
+            rc = run_wta_median(c, n, false, d_disp, st);
+    }
     c->last_n = n;
+    if (!rc)
+        rc = scratch_release(c, st);
     return rc;
 }
 
@@ -570,7 +630,7 @@ int ns_group(sgmx_ctx *c, int n, const float *left, int thr, uint16_t *d_disp, h
     }
     HIPCHK(c, hipGetLastError());
     c->last_n = n;
-    return SGMX_OK;
+    return scratch_release(c, st);
 }
 
 int ns_check(sgmx_ctx *c, int W, int H, int D, int thr)
@@ -591,17 +651,38 @@ int ns_check(sgmx_ctx *c, int W, int H, int D, int thr)
     return SGMX_OK;
 }
 
+// uint16 guarantees of the census path: L_k <= 255*(k+1) + P2 on any pixel, so S <= 36*255 + 8*P2, and the
+// "no disparity" sentinel 0x7FFF must stay above every L + P1 (sgmx_kernels.hpp INF16).  Checked on the
+// census entry points only: the float pipelines hold no uint16 volume and take any penalty, as the reference does.
+int check_census_penalties(sgmx_ctx *c)
+{
+    const sgmx_params &p = c->prm;
+    if (36LL * 255 + 8LL * p.penalty2 > 65535 || 9LL * 255 + p.penalty2 + p.penalty1 >= 0x7FFF || 0x7FFFLL + p.penalty1 > 65535)
+        return fail(c, SGMX_ERR_RANGE, "penalties too large for uint16 path costs (need 9180 + 8*P2 <= 65535)");
+    return SGMX_OK;
+}
+
 int check_size(sgmx_ctx *c, int W, int H, bool census)
 {
     if (!c)
         return SGMX_ERR_INVALID_ARG;
+    if (census) {
+        const int rc = check_census_penalties(c);
+        if (rc)
+            return rc;
+    }
     const int m = census ? (c->prm.window_sz - 1) / 2 : 0;
     if (W - 2 * m < 1 || H - 2 * m < 1)
         return fail(c, SGMX_ERR_INVALID_ARG, "image smaller than the census window");
-    if ((size_t)(W - 2 * m) * (H - 2 * m) * c->Dp >= (size_t)1 << 31)
+    const int Dp = census && c->fast ? c->DpF : c->Dp;
+    if ((size_t)(W - 2 * m) * (H - 2 * m) * Dp >= (size_t)1 << 31)
         return fail(c, SGMX_ERR_INVALID_ARG, "cost volume of one pair exceeds 2^31 voxels");
-    if ((size_t)(W - 2 * m) * 16 + 8192 > 160 * 1024)
-        return fail(c, SGMX_ERR_INVALID_ARG, "image wider than the per-row LDS budget of the WTA kernel (9728 pixels)");
+    // dynamic LDS of the WTA kernel this call will launch (a workgroup may use all 160 KiB of a CU)
+    const int w = W - 2 * m;
+    const size_t lds = census ? (c->fast ? wta3_lds_bytes(c->DpF, w) : (size_t)w * 8) : (size_t)w * 16;
+    if (lds > 160 * 1024)
+        return fail(c, SGMX_ERR_INVALID_ARG, "image too wide for the per-row LDS tables of the WTA kernel (" +
+                                                 std::to_string(lds) + " bytes needed, 163840 available)");
     return SGMX_OK;
 }
 
@@ -631,14 +712,10 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "window_sz must be odd and in [1, 31]");
     if (p.num_paths != 4 && p.num_paths != 8)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "num_paths must be 4 or 8");
-    if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 ||
-        (p.flags & ~(SGMX_FLAG_MATERIALIZE | SGMX_FLAG_NO_SMALL_GROUPS)) != 0)
+    if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 || (p.flags & ~SGMX_FLAG_MATERIALIZE) != 0)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "negative penalty, bad max_batch or unknown flags");
-    // uint16 guarantees: L_k <= 255*(k+1) + P2 on any pixel, so S <= 36*255 + 8*P2, and the
-    // "no disparity" sentinel 0x7FFF must stay above every L + P1 (sgmx_kernels.hpp INF16).
-    if (36LL * 255 + 8LL * p.penalty2 > 65535 || 9LL * 255 + p.penalty2 + p.penalty1 >= 0x7FFF ||
-        0x7FFFLL + p.penalty1 > 65535)
-        return fail(nullptr, SGMX_ERR_RANGE, "penalties too large for uint16 path costs (need 9180 + 8*P2 <= 65535)");
+    if (p.device < 0 || p.device >= 64)
+        return fail(nullptr, SGMX_ERR_INVALID_ARG, "device ordinal out of range");
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev <= 0)
@@ -654,14 +731,11 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->R = p.disp_range <= 128 ? 1 : (p.disp_range <= 256 ? 2 : 4);
     c->Dp = 128 * c->R;
     c->fast = p.penalty2 <= 255 && !(p.flags & SGMX_FLAG_MATERIALIZE);
-    // No size switch any more: with the sweeps' work spread over all XCDs the volume-free kernels are the
-    // faster ones at every group size measured (one KITTI pair 1.12 against 1.09 ms, Tsukuba 0.39 / 0.51,
-    // one 4K pair 11.4 / 22.3 ms), so SGMX_FLAG_NO_SMALL_GROUPS is accepted and has no effect.
-    c->small_n = 0;
     c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : (p.disp_range <= 256 ? 8 : (p.disp_range <= 384 ? 12 : 16))));
     c->DpF = 32 * c->RP;
     bool ok = hipSetDevice(p.device) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess &&
-              hipStreamCreate(&c->copy_stream) == hipSuccess;
+              hipStreamCreate(&c->copy_stream) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++)
         ok = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming) == hipSuccess &&
@@ -689,6 +763,8 @@ void sgmx_destroy(sgmx_ctx *ctx)
         for (hipEvent_t ev : {ctx->ev_in[i], ctx->ev_done[i], ctx->ev_out[i]})
             if (ev)
                 (void)hipEventDestroy(ev);
+    if (ctx->ev_scratch)
+        (void)hipEventDestroy(ctx->ev_scratch);
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream)
@@ -705,10 +781,10 @@ int sgmx_compute_census_u8_dev(sgmx_ctx *c, int n, const uint8_t *d_left, const 
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->prm.device));
-    rc = ensure_scratch(c, 1, W, H);
+    hipStream_t st = (hipStream_t)stream;
+    rc = ensure_scratch(c, 1, W, H, st);
     if (rc)
         return rc;
-    hipStream_t st = (hipStream_t)stream;
     const size_t nfull = (size_t)W * H;
     for (int i = 0; i < n; i += c->prm.max_batch) {
         const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
@@ -747,7 +823,7 @@ int sgmx_compute_census_u8_batch(sgmx_ctx *c, int n, const uint8_t *left, const 
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->prm.device));
-    rc = ensure_scratch(c, 1, W, H);
+    rc = ensure_scratch(c, 1, W, H, c->own_stream);
     if (rc)
         return rc;
     // Launch groups are pipelined over two staging sets: while group g computes on the compute stream,
@@ -820,10 +896,10 @@ int sgmx_compute_census_u8(sgmx_ctx *c, const uint8_t *left, const uint8_t *righ
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->prm.device));
-    rc = ensure_scratch(c, 1, W, H);
+    hipStream_t st = c->own_stream;
+    rc = ensure_scratch(c, 1, W, H, st);
     if (rc)
         return rc;
-    hipStream_t st = c->own_stream;
     // dense rows go as one linear copy (a 2-D copy from pageable memory is several ms slower)
     if (stride_left == W)
         HIPCHK(c, hipMemcpyAsync(c->d_left, left, (size_t)W * H, hipMemcpyHostToDevice, st));
@@ -855,10 +931,10 @@ int sgmx_compute_cost_f32_dev(sgmx_ctx *c, int n, const float *d_cost, int W, in
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->prm.device));
-    rc = ensure_scratch(c, 2, W, H);
+    hipStream_t st = (hipStream_t)stream;
+    rc = ensure_scratch(c, 2, W, H, st);
     if (rc)
         return rc;
-    hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)W * H;
     for (int i = 0; i < n; i += c->prm.max_batch) {
         const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
@@ -877,6 +953,8 @@ int sgmx_compute_cost_f32_dev(sgmx_ctx *c, int n, const float *d_cost, int W, in
         if (rc)
             return rc;
         c->last_n = g;
+        if ((rc = scratch_release(c, st)))
+            return rc;
     }
     return SGMX_OK;
 }
@@ -897,7 +975,7 @@ int sgmx_compute_cost_f32(sgmx_ctx *c, const float *cost, int W, int H, int D, u
     hipStream_t st = c->own_stream;
     hipError_t e = hipMemcpyAsync(d_in, cost, npix * D * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        rc = ensure_scratch(c, 2, W, H);
+        rc = ensure_scratch(c, 2, W, H, st);
         if (!rc)
             rc = sgmx_compute_cost_f32_dev(c, 1, d_in, W, H, D, c->d_out, st);
         if (!rc)
@@ -921,7 +999,7 @@ int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->prm.device));
-    rc = ensure_scratch(c, 2, W, H);
+    rc = ensure_scratch(c, 2, W, H, c->own_stream);
     if (rc)
         return rc;
     const size_t npix = (size_t)W * H, nb = npix * K * sizeof(float);
@@ -939,6 +1017,8 @@ int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc
         if (!rc)
             rc = run_wta_median(c, 1, true, c->d_out, st);
         c->last_n = 1;
+        if (!rc)
+            rc = scratch_release(c, st);
         if (!rc)
             e = hipMemcpyAsync(disp, c->d_out, npix * 2, hipMemcpyDeviceToHost, st);
     }
@@ -962,9 +1042,9 @@ int sgmx_sgmstereo_cost_f32_dev(sgmx_ctx *c, int n, const float *d_cost, int W, 
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->prm.device));
-    if ((rc = ensure_scratch(c, 3, W, H)))
-        return rc;
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_scratch(c, 3, W, H, st)))
+        return rc;
     const size_t npix = (size_t)W * H;
     for (int i = 0; i < n; i += c->prm.max_batch) {
         const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
@@ -997,7 +1077,7 @@ int sgmx_sgmstereo_cost_f32(sgmx_ctx *c, const float *cost, int W, int H, int D,
     hipStream_t st = c->own_stream;
     hipError_t e = hipMemcpyAsync(d_in, cost, npix * D * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        rc = ensure_scratch(c, 3, W, H);
+        rc = ensure_scratch(c, 3, W, H, st);
         if (!rc)
             rc = sgmx_sgmstereo_cost_f32_dev(c, 1, d_in, W, H, D, consistency_threshold, c->d_out, st);
         if (!rc)
@@ -1023,7 +1103,7 @@ int sgmx_sgmstereo_desc_f32(sgmx_ctx *c, const float *desc_left, const float *de
     if (rc)
         return rc;
     HIPCHK(c, hipSetDevice(c->prm.device));
-    if ((rc = ensure_scratch(c, 3, W, H)))
+    if ((rc = ensure_scratch(c, 3, W, H, c->own_stream)))
         return rc;
     const size_t npix = (size_t)W * H, nb = npix * K * sizeof(float);
     float *d_f = nullptr;
@@ -1269,9 +1349,20 @@ int sgmx_hamming_matrix_u16(sgmx_ctx *c, uint16_t *dis, const uint8_t *a, const 
 
 // Thresholded matching of binary signatures (core/hamming.c:300-322, 385-407, 725-765, 810-839).  cross: one
 // set against itself, pairs j > i only.  idx == nullptr: count only.
+// records != nullptr: the allocating forms (match_hamming_thres, crossmatch_hamming; core/hamming.c:533-577, 768-807):
+// once the count is known a buffer of max(bufsize, count, 1) hammatch_t records is malloc'ed into *records (the
+// reference mallocs bufsize and grows by realloc; the caller frees it either way) and filled in loop order.
 static int ham_match(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, long n1, long n2, int ht, int ncodes, bool cross,
-                     int *idx, uint16_t *hams, size_t capacity, size_t *nptr)
+                     int *idx, uint16_t *hams, size_t capacity, size_t *nptr, sgmx_hammatch **records = nullptr,
+                     size_t bufsize = 0)
 {
+    if (records) {
+        if (!c || !nptr)
+            return fail(c, SGMX_ERR_INVALID_ARG, "null pointer");
+        *records = static_cast<sgmx_hammatch *>(std::malloc((bufsize ? bufsize : 1) * sizeof(sgmx_hammatch)));
+        if (!*records)
+            return fail(c, SGMX_ERR_OOM, "host allocation failed");
+    }
     if (!c || !nptr || n1 < 0 || n2 < 0 || ncodes < 1 || n1 > 0x7fffffffL || n2 > 0x7fffffffL || (n1 > 0 && !bs1) ||
         (!cross && n2 > 0 && !bs2) || (idx && !hams))
         return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
@@ -1319,11 +1410,19 @@ static int ham_match(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, long n
         return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP, std::string("hamming match: ") + hipGetErrorString(e));
     }
     *nptr = (size_t)total;
-    if (!idx || total == 0) {
+    if ((!idx && !records) || total == 0) {
         cleanup();
         return SGMX_OK;
     }
-    if ((size_t)total > capacity) {
+    if (records && (size_t)total > (bufsize ? bufsize : 1)) {
+        void *grown = std::realloc(*records, (size_t)total * sizeof(sgmx_hammatch));
+        if (!grown) {
+            cleanup();
+            return fail(c, SGMX_ERR_OOM, "host allocation failed");
+        }
+        *records = static_cast<sgmx_hammatch *>(grown);
+    }
+    if (!records && (size_t)total > capacity) {
         cleanup();
         return fail(c, SGMX_ERR_INVALID_ARG, "hamming match: more matches than the caller's capacity (count first)");
     }
@@ -1333,11 +1432,22 @@ static int ham_match(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, long n
     if (e == hipSuccess) {
         hipLaunchKernelGGL(ham_emit_kernel, grid, dim3(256), 0, st, d_a, d_b, (int)n1, (int)n2, ncodes, ht, cross ? 1 : 0, d_cnt,
                            total, d_idx, d_h);
-        e = hipMemcpyAsync(idx, d_idx, (size_t)total * 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (!records)
+            e = hipMemcpyAsync(idx, d_idx, (size_t)total * 2 * sizeof(int), hipMemcpyDeviceToHost, st);
     }
-    if (e == hipSuccess)
+    int *d_rec = nullptr;
+    if (e == hipSuccess && !records)
         e = hipMemcpyAsync(hams, d_h, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && records) {
+        static_assert(sizeof(sgmx_hammatch) == 12, "hammatch_t is two ints and a uint16 (core/hamming.h:52-56)");
+        e = hipMalloc((void **)&d_rec, (size_t)total * sizeof(sgmx_hammatch));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(ham_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_idx, d_h, total, d_rec);
+            e = hipMemcpyAsync(*records, d_rec, (size_t)total * sizeof(sgmx_hammatch), hipMemcpyDeviceToHost, st);
+        }
+    }
     const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_rec);
     cleanup();
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP,
@@ -1371,6 +1481,116 @@ int sgmx_crossmatch_hamming_prealloc(sgmx_ctx *c, const uint8_t *dbs, long n, in
     return ham_match(c, dbs, dbs, n, n, ht, ncodes, true, idx, hams, capacity, nptr);
 }
 
+int sgmx_match_hamming_thres(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, int n1, int n2, int ht, int ncodes,
+                             size_t bufsize, sgmx_hammatch **hmptr, size_t *nptr)
+{
+    if (!hmptr)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null output pointer");
+    return ham_match(c, bs1, bs2, n1, n2, ht, ncodes, false, nullptr, nullptr, 0, nptr, hmptr, bufsize);
+}
+
+int sgmx_crossmatch_hamming(sgmx_ctx *c, const uint8_t *dbs, long n, int ht, int ncodes, long bufsize, sgmx_hammatch **hmptr,
+                            size_t *nptr)
+{
+    if (!hmptr || bufsize < 0)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null output pointer or negative bufsize");
+    return ham_match(c, dbs, dbs, n, n, ht, ncodes, true, nullptr, nullptr, 0, nptr, hmptr, (size_t)bufsize);
+}
+
+// compute_hamming_thread (core/hamming.c:849-860) is compute_hamming with the rows of the matrix dealt to OpenMP
+// threads: the same matrix.  The GPU form is parallel either way.
+int sgmx_compute_hamming_thread(sgmx_ctx *c, uint16_t *dis, const uint8_t *a, const uint8_t *b, int na, int nb, int ncodes)
+{
+    return sgmx_hamming_matrix_u16(c, dis, a, b, na, nb, ncodes);
+}
+
+int sgmx_match_hamming_thres_nt(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, int n1, int n2, int ht, int ncodes, int nt,
+                                int **keys, uint16_t **ham, size_t *nmatches)
+{
+    (void)nt; // the reference's thread count: does not change the result there either
+    if (!c || !bs1 || !bs2 || !keys || !ham || !nmatches || n1 < 1 || n2 < 1 || ncodes < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
+    *keys = nullptr;
+    *ham = nullptr;
+    *nmatches = 0;
+    const int nblock1 = 1 + (n1 - 1) / HAMBLOCK, nblock2 = 1 + (n2 - 1) / HAMBLOCK;
+    if (nblock1 != nblock2)
+        return fail(c, SGMX_ERR_INVALID_ARG,
+                    "match_hamming_thres_nt: the reference indexes both sets by bl / nblock1 and bl % nblock1 "
+                    "(core/hamming.c:876-877), which leaves the sets unless both have the same number of 128-blocks");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    hipStream_t st = c->own_stream;
+    const long nitems = (long)nblock1 * nblock2 * HAMBLOCK;
+    const HamBlocked g{nblock1, n1, n2};
+    uint8_t *d_a = nullptr, *d_b = nullptr;
+    unsigned long long *d_cnt = nullptr, total = 0;
+    int *d_idx = nullptr;
+    uint16_t *d_h = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_a);
+        (void)hipFree(d_b);
+        (void)hipFree(d_cnt);
+        (void)hipFree(d_idx);
+        (void)hipFree(d_h);
+    };
+    hipError_t e = hipMalloc((void **)&d_a, (size_t)n1 * ncodes + 4);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_b, (size_t)n2 * ncodes + 4);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_cnt, ((size_t)nitems + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_a, bs1, (size_t)n1 * ncodes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_b, bs2, (size_t)n2 * ncodes, hipMemcpyHostToDevice, st);
+    const dim3 grid((unsigned)((nitems + 3) / 4));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ham_count_blocked_kernel, grid, dim3(256), 0, st, d_a, d_b, g, nitems, ncodes, ht, d_cnt);
+        hipLaunchKernelGGL(ham_scan_kernel, dim3(1), dim3(1024), 0, st, d_cnt, (int)nitems, d_cnt + nitems);
+        e = hipMemcpyAsync(&total, d_cnt + nitems, sizeof(total), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (e == hipSuccess) {
+        // malloc(0) may return NULL: keep one element so that a caller's free() and pointer checks behave
+        *keys = static_cast<int *>(std::malloc(((size_t)total ? (size_t)total : 1) * 2 * sizeof(int)));
+        *ham = static_cast<uint16_t *>(std::malloc(((size_t)total ? (size_t)total : 1) * sizeof(uint16_t)));
+        if (!*keys || !*ham) {
+            std::free(*keys);
+            std::free(*ham);
+            *keys = nullptr;
+            *ham = nullptr;
+            cleanup();
+            return fail(c, SGMX_ERR_OOM, "host allocation failed");
+        }
+    }
+    if (e == hipSuccess && total > 0) {
+        e = hipMalloc((void **)&d_idx, (size_t)total * 2 * sizeof(int));
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&d_h, (size_t)total * sizeof(uint16_t));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(ham_emit_blocked_kernel, grid, dim3(256), 0, st, d_a, d_b, g, nitems, ncodes, ht, d_cnt, d_idx, d_h);
+            e = hipMemcpyAsync(*keys, d_idx, (size_t)total * 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(*ham, d_h, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, st);
+        const hipError_t e2 = hipStreamSynchronize(st);
+        if (e == hipSuccess)
+            e = e2;
+    }
+    cleanup();
+    if (e != hipSuccess) {
+        std::free(*keys);
+        std::free(*ham);
+        *keys = nullptr;
+        *ham = nullptr;
+        return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP, std::string("hamming match (blocked): ") + hipGetErrorString(e));
+    }
+    *nmatches = (size_t)total;
+    return SGMX_OK;
+}
+
+void sgmx_free(void *ptr) { std::free(ptr); }
+
 static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16_t *raw)
 {
     if (!c)
@@ -1381,7 +1601,7 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
         return fail(c, SGMX_ERR_INVALID_ARG, "pair index outside the last launch group");
     HIPCHK(c, hipSetDevice(c->prm.device));
     HIPCHK(c, hipDeviceSynchronize());
-    const int D = c->prm.disp_range, Dp = (mode == 1 && c->last_fast) ? c->DpF : c->Dp;
+    const int D = c->prm.disp_range, Dp = (mode == 1 && c->fast) ? c->DpF : c->Dp;
     const size_t npix = (size_t)c->w * c->h, tot = npix * D;
     const size_t esz_c = mode == 1 ? 1 : 4, esz_s = mode == 1 ? 2 : 4;
     void *tmp = nullptr;
@@ -1389,7 +1609,7 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
     hipStream_t st = c->own_stream;
     hipError_t e = hipSuccess;
     const unsigned nb = (unsigned)((tot + 255) / 256);
-    const bool fast = mode == 1 && c->last_fast;
+    const bool fast = mode == 1 && c->fast;
     if (C && mode == 1) {
         const uint8_t *src = (const uint8_t *)c->d_C + index * c->bytes_C;
         uint8_t *vol = nullptr;
@@ -1412,7 +1632,7 @@ static int get_stages(sgmx_ctx *c, int mode, int index, void *C, void *S, uint16
     }
     if (S && e == hipSuccess) {
         if (fast) {
-            const SumArgs sa = sum_args(c);
+            const SumArgs sa = sum_args(c, ctx_view(c));
             const size_t thr = npix * 16;
             const dim3 grid((unsigned)((thr + 255) / 256));
             if (c->RP == 1)
@@ -1490,7 +1710,7 @@ int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
     hipError_t e = hipMemsetAsync(d_o, 0, nfull, st);
     const uint8_t *src = (const uint8_t *)c->d_C + index * c->bytes_C;
     uint8_t *vol = nullptr;
-    if (c->last_fast) {
+    if (c->fast) {
         if (hipMalloc((void **)&vol, (size_t)c->w * c->h * c->DpF) != hipSuccess || materialize_cost(c, index, vol, st) != SGMX_OK) {
             (void)hipFree(d_o);
             (void)hipFree(vol);
@@ -1499,7 +1719,7 @@ int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
         src = vol;
     }
     hipLaunchKernelGGL(data_cost_wta_kernel, dim3((c->w + 255) / 256, c->h), dim3(256), 0, st, src, c->w, c->h,
-                       c->prm.disp_range, c->last_fast ? c->DpF : c->Dp, c->m, d_o);
+                       c->prm.disp_range, c->fast ? c->DpF : c->Dp, c->m, d_o);
     if (e == hipSuccess)
         e = hipMemcpyAsync(out, d_o, nfull, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);

@@ -120,14 +120,16 @@ int main(int argc, char **argv)
 {
     return sgmx::cli::guarded("evaluate_stereo", [&]() {
         const sgmx::cli::Args a = sgmx::cli::parse(argc, argv);
-        if (a.pos.size() != 1) {
-            std::cout << "Usage: ./eval_stereo result_dir" << std::endl;
+        // The reference compiles its ground-truth folder in (evaluate_stereo.cc:129, a path under the author's
+        // home directory); here it is a required option.
+        if (a.pos.size() != 1 || !a.has("gt-folder")) {
+            std::cout << "Usage: ./eval_stereo result_dir --gt-folder <KITTI stereo training folder holding disp_noc/ and disp_occ/> "
+                         "[--count 200] [--device 0]" << std::endl;
             return 1;
         }
         const std::string result_dir = a.pos[0];
         Errors ke;
-        eval(result_dir, a.str("gt-folder", "/home/kivan/datasets/KITTI/stereo/data_stereo_flow/training/"), a.num("count", 200),
-             a.num("device", 0), ke);
+        eval(result_dir, a.str("gt-folder", ""), a.num("count", 200), a.num("device", 0), ke);
         // the reference appends the line whether or not eval succeeded (:318-326)
         std::ofstream ofile(result_dir + "/../stats.txt", std::ofstream::app);
         ofile << std::fixed << std::setprecision(2) << ke.out_noc << "\t" << ke.out_all << "\t" << ke.avg_noc << "\t";

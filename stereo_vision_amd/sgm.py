@@ -216,6 +216,61 @@ class StereoSGM(Engine):
         assert got.value == n
         return idx, hams
 
+    def _take_records(self, hm, n):
+        """Copy n hammatch_t records (core/hamming.h:52-56) out of a malloc'ed array and release it."""
+        rec = np.dtype([("qid", np.int32), ("bid", np.int32), ("score", np.uint16), ("_pad", np.uint16)])
+        try:
+            out = np.ctypeslib.as_array(C.cast(hm, C.POINTER(C.c_uint8)), (n * 12,)).view(rec).copy() if n else np.empty(0, rec)
+        finally:
+            self.lib.sgmx_free(hm)
+        return np.stack([out["qid"], out["bid"]], 1).astype(np.int32), out["score"].copy()
+
+    def match_hamming_thres_alloc(self, bs1, bs2, ht, bufsize=16):
+        """match_hamming_thres (core/hamming.h:84-86): the library allocates the hammatch_t array."""
+        a = np.ascontiguousarray(bs1, np.uint8)
+        b = np.ascontiguousarray(bs2, np.uint8)
+        hm, n = C.c_void_p(), C.c_size_t(0)
+        rc = self.lib.sgmx_match_hamming_thres(self.h, _ptr(a), _ptr(b), a.shape[0], b.shape[0], int(ht), a.shape[1],
+                                               int(bufsize), C.byref(hm), C.byref(n))
+        if rc:
+            self.lib.sgmx_free(hm)
+            self.check(rc)
+        return self._take_records(hm, n.value)
+
+    def crossmatch_hamming_alloc(self, dbs, ht, bufsize=16):
+        """crossmatch_hamming (core/hamming.h:95-96)."""
+        a = np.ascontiguousarray(dbs, np.uint8)
+        hm, n = C.c_void_p(), C.c_size_t(0)
+        rc = self.lib.sgmx_crossmatch_hamming(self.h, _ptr(a), a.shape[0], int(ht), a.shape[1], int(bufsize), C.byref(hm),
+                                              C.byref(n))
+        if rc:
+            self.lib.sgmx_free(hm)
+            self.check(rc)
+        return self._take_records(hm, n.value)
+
+    def hamming_matrix_thread(self, a, b):
+        """compute_hamming_thread (core/hamming.h:108-109): the same matrix as compute_hamming."""
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        out = np.empty((b.shape[0], a.shape[0]), np.uint16)
+        self.check(self.lib.sgmx_compute_hamming_thread(self.h, _ptr(out), _ptr(a), _ptr(b), a.shape[0], b.shape[0], a.shape[1]))
+        return out
+
+    def match_hamming_thres_nt(self, bs1, bs2, ht, nt=4):
+        """match_hamming_thres_nt (core/hamming.h:111-112): matches block pair by block pair, block-local indices."""
+        a = np.ascontiguousarray(bs1, np.uint8)
+        b = np.ascontiguousarray(bs2, np.uint8)
+        keys, ham, n = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        self.check(self.lib.sgmx_match_hamming_thres_nt(self.h, _ptr(a), _ptr(b), a.shape[0], b.shape[0], int(ht), a.shape[1],
+                                                        int(nt), C.byref(keys), C.byref(ham), C.byref(n)))
+        try:
+            k = np.ctypeslib.as_array(C.cast(keys, C.POINTER(C.c_int32)), (max(n.value, 1), 2))[:n.value].copy()
+            h = np.ctypeslib.as_array(C.cast(ham, C.POINTER(C.c_uint16)), (max(n.value, 1),))[:n.value].copy()
+        finally:
+            self.lib.sgmx_free(keys)
+            self.lib.sgmx_free(ham)
+        return k, h
+
     def stages(self, H, W, index=0):
         m = self.margin
         h, w, D = H - 2 * m, W - 2 * m, self.params.disp_range
@@ -316,6 +371,10 @@ class SGMStereo:
             raise ValueError("smoothness penalty value is less than zero")
         if P1 >= P2:
             raise ValueError("small value of smoothness penalty must be smaller than large penalty value")
+        # The reference keeps the penalties as float (sgm_stereo.h:63-64); this engine's parameter block is the
+        # four ints of StereoSGMParams, so fractional penalties are refused rather than silently truncated.
+        if float(P1) != int(P1) or float(P2) != int(P2):
+            raise ValueError("smoothness penalties must be whole numbers (sgmx_params holds ints)")
         self.P1, self.P2 = int(P1), int(P2)
 
     def SetConsistencyThreshold(self, consistency_threshold):

@@ -45,16 +45,19 @@ def _create(**kw):
 
 
 @pytest.mark.parametrize("kw", [dict(disp_range=1), dict(disp_range=513), dict(num_paths=5), dict(penalty1=-1),
-                                dict(window_sz=-3), dict(window_sz=4), dict(flags=4), dict(max_batch=-2)])
+                                dict(window_sz=-3), dict(window_sz=4), dict(flags=4), dict(flags=2), dict(max_batch=-2),
+                                dict(device=64)])
 def test_create_rejects_bad_parameters(kw):
     rc, msg = _create(**kw)
     assert rc == 1 and msg  # SGMX_ERR_INVALID_ARG, with text
 
 
-def test_create_rejects_penalties_beyond_uint16_guard():
-    # 36*255 + 8*P2 must fit uint16 (include/sgmx.h)
-    assert _create(penalty2=7045)[0] == 2
-    assert _create(penalty2=7044, penalty1=7044)[0] in (0, 3)  # valid: OK on a GPU box, NO_DEVICE here
+def test_create_leaves_the_uint16_guard_to_the_census_calls():
+    # 36*255 + 8*P2 must fit uint16 on the census path (include/sgmx.h); the float pipelines take any penalty
+    # (sgm.h:129-157), so create accepts it and the census entry points answer SGMX_ERR_RANGE
+    # (tests/test_parity_gpu.py::test_float_path_takes_penalties_beyond_the_uint16_guard)
+    assert _create(penalty2=7045)[0] in (0, 3)  # OK on a GPU box, NO_DEVICE here
+    assert _create(penalty2=7044, penalty1=7044)[0] in (0, 3)
 
 
 def test_null_arguments():
@@ -83,3 +86,14 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_hamming_compat_library_exports_the_reference_names():
+    """libhamming_sgmx.so carries every function core/hamming.h:62-112 declares (no compute call without a GPU)."""
+    path = os.path.join(ROOT, "stereo_vision_amd", "libhamming_sgmx.so")
+    assert os.path.exists(path), "run make -C stereo_vision_amd/host"
+    L = C.CDLL(path)
+    for name in ("hamming", "compute_hamming", "match_hamming_count", "crossmatch_hamming_count", "match_hamming_thres",
+                 "match_hamming_thres_prealloc", "crossmatch_hamming", "crossmatch_hamming_prealloc",
+                 "compute_hamming_thread", "match_hamming_thres_nt"):
+        assert hasattr(L, name), name

@@ -197,8 +197,7 @@ def test_4k_stress_two_formulations_agree():
     sys.path.insert(0, ROOT)
     from bench import synthetic_pair
     left, right = synthetic_pair(4242, 2160, 3840, 240)
-    fast = sv.StereoSGM(sv.StereoSGMParams(disp_range=256, window_sz=5, penalty1=3, penalty2=60,
-                                           flags=sv.FLAG_NO_SMALL_GROUPS))
+    fast = sv.StereoSGM(sv.StereoSGMParams(disp_range=256, window_sz=5, penalty1=3, penalty2=60))
     a = fast.compute(left, right)
     b = fast.compute(left, right)
     assert np.array_equal(a, b)

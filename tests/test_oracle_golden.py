@@ -238,3 +238,23 @@ def test_disparities_past_255_wrap_like_the_reference_builds(oracle):
         ds = np.float32(0.5) * (cr - cl) / ((cc - cl) if cr < cl else (cc - cr))
         v = int(np.floor(256.0 * float(np.float32(d) + ds) + 0.5))  # std::round on a positive value
         assert v >= 65536 and int(raw[y, x]) == v % 65536
+
+
+@pytest.mark.parametrize("ncodes,ht", [(4, 10), (8, 24), (16, 52), (5, 14)])
+def test_hamming_allocating_and_threaded_forms_vs_reference_build(oracle, ncodes, ht):
+    """The rest of core/hamming.h (84-96, 108-112) in the reference build itself: match_hamming_thres / crossmatch_hamming
+    return the prealloc forms' matches as hammatch_t records; compute_hamming_thread == compute_hamming;
+    match_hamming_thres_nt == the 128 x 128 block-pair order with block-local indices that the restatement spells out."""
+    rng = np.random.default_rng(ncodes * 7 + ht)
+    a = rng.integers(0, 256, size=(300, ncodes)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(270, ncodes)).astype(np.uint8)
+    if oracle.ref_match_hamming(a, b, ht) is None:
+        pytest.skip("oracle/_ref/libhamming_ref.so not built (reference tree not mounted)")
+    for cross in (False, True):
+        idx, hams = oracle.match_hamming(a, b, ht, cross)
+        ridx, rh = oracle.ref_match_hamming_alloc(a, b, ht, cross, bufsize=3)  # small: the reference grows it
+        assert np.array_equal(ridx, idx) and np.array_equal(rh, hams)
+    assert np.array_equal(oracle.ref_hamming_matrix_thread(a, b), oracle.hamming_matrix(a, b))
+    k, h = oracle.match_hamming_blocked(a, b, ht)
+    rk, rh = oracle.ref_match_hamming_thres_nt(a, b, ht)
+    assert len(h) > 0 and np.array_equal(rk, k) and np.array_equal(rh, h)

@@ -119,7 +119,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
+@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
 def test_pipeline_stages_bit_exact(oracle, case, flags):
     """Every stage of both census formulations: the default one (C recomputed from the census
@@ -160,13 +160,13 @@ def test_seeded_random_configurations(oracle, case):
     H, W, D, wsz, P1, P2, paths = case
     left, right = synth_pair(H * 977 + W * 13 + D, H, W, max(1, min(D, W // 2)))
     want = oracle.sgm_census(left, right, D, wsz, P1, P2, paths)
-    for flags in (2, 1):
+    for flags in (0, 1):
         e = make(disp_range=D, window_sz=wsz, penalty1=P1, penalty2=P2, num_paths=paths, flags=flags)
         assert np.array_equal(e.compute(left, right), want), "flags=%d" % flags
         e.close()
 
 
-@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
+@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
 @pytest.mark.parametrize("shape", [(5, 5), (6, 40), (40, 6), (5, 300), (6, 6), (7, 5), (5, 7)])
 def test_degenerate_shapes(oracle, shape, flags):
     """Cropped images of 1 x 1, one row, one column, 2 x 2; D larger than the width."""
@@ -189,28 +189,31 @@ def test_strided_input_and_reuse(oracle):
 
 
 # ---------------------------------------------------------------- golden fixtures
-@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
-def test_tsukuba_golden(oracle, tsukuba, flags):
+def _golden_keys():
     from test_oracle_golden import KNOWN
-    for paths in (8, 4):
-        disp = make(disp_range=16, window_sz=5, num_paths=paths, flags=flags).compute(*tsukuba)
-        s, nz, fnv = KNOWN[("tsukuba", 16, 5, paths)]
-        assert int(disp.sum(dtype=np.uint64)) == s and int(np.count_nonzero(disp)) == nz
-        assert oracle.fnv_u16(disp) == fnv
+    return sorted(KNOWN)
 
 
-@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
-def test_kitti_golden_full_size(oracle, kitti, flags):
-    """BASELINE config 2 at full size: KITTI 1241x376, D=128, 8 paths, wsz 5 and 3."""
-    from test_oracle_golden import KNOWN
-    for wsz in (5, 3):
-        disp = make(disp_range=128, window_sz=wsz, flags=flags).compute(*kitti)
-        s, nz, fnv = KNOWN[("kitti", 128, wsz, 8)]
-        assert int(disp.sum(dtype=np.uint64)) == s and int(np.count_nonzero(disp)) == nz
-        assert oracle.fnv_u16(disp) == fnv
+@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
+@pytest.mark.parametrize("key", _golden_keys(), ids=lambda k: "%s-D%d-w%d-p%d" % k)
+def test_reference_known_answers(oracle, tsukuba, kitti, key, flags):
+    """All six known answers SURVEY.md 8c records for recon::StereoSGM::compute on the reference's own fixtures
+    (Tsukuba D=16 wsz 5 / 3, 8 / 4 paths = BASELINE config 1; KITTI 1241x376 D=128 wsz 5 / 3, 8 / 4 paths = BASELINE
+    config 2 at full size), both formulations; the two "per-direction reset" hashes are what the output must NOT be."""
+    from test_oracle_golden import KNOWN, RESET_FNV
+    name, D, wsz, paths = key
+    left, right = tsukuba if name == "tsukuba" else kitti
+    e = make(disp_range=D, window_sz=wsz, num_paths=paths, flags=flags)
+    disp = e.compute(left, right)
+    e.close()
+    s, nz, fnv = KNOWN[key]
+    assert int(disp.sum(dtype=np.uint64)) == s and int(np.count_nonzero(disp)) == nz
+    assert oracle.fnv_u16(disp) == fnv
+    if key in RESET_FNV:
+        assert oracle.fnv_u16(disp) != RESET_FNV[key]
 
 
-@pytest.mark.parametrize("flags", [2, 1, 0], ids=["fast", "materialized", "adaptive"])
+@pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
 def test_kitti_stages_vs_oracle(oracle, kitti, flags):
     left, right = kitti
     e = make(disp_range=128, window_sz=5, flags=flags)
@@ -227,7 +230,7 @@ def test_batch_chunks_equal_single(oracle):
     pairs = [synth_pair(100 + i, H, W, 40) for i in range(n)]
     L = np.stack([p[0] for p in pairs])
     R = np.stack([p[1] for p in pairs])
-    e = make(disp_range=64, window_sz=5, max_batch=2, flags=sv.FLAG_NO_SMALL_GROUPS)  # 5 pairs -> groups of 2, 2, 1
+    e = make(disp_range=64, window_sz=5, max_batch=2)  # 5 pairs -> groups of 2, 2, 1
     got = e.compute_batch(L, R)
     for i in range(n):
         assert np.array_equal(got[i], oracle.sgm_census(L[i], R[i], 64, 5, 3, 60, 8)), i
@@ -256,7 +259,7 @@ def test_device_entry_point_with_torch_memory(oracle):
     L = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
     R = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
     out = torch.zeros((n, H, W), dtype=torch.int16, device="cuda")
-    e = make(disp_range=128, window_sz=5, max_batch=4, flags=sv.FLAG_NO_SMALL_GROUPS)
+    e = make(disp_range=128, window_sz=5, max_batch=4)
     e.compute_device(L.data_ptr(), R.data_ptr(), out.data_ptr(), n, W, H, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(np.uint16)
@@ -389,3 +392,134 @@ def test_depth_from_disparity(oracle):
     assert oracle.depth_image(disp, 7215.0, 0.54) is None
     with pytest.raises(sv.SgmxError):
         e.depth_image(disp, 7215.0, 0.54)  # 100 f b / d >= 65536: the reference throws
+
+
+def test_float_path_takes_penalties_beyond_the_uint16_guard(oracle):
+    """The uint16 path-cost guard (P2 <= 7044) belongs to the census entry points only: recon::SGM / SGMStereo keep
+    float costs and take any penalty (sgm.h:129-157), while a census call on such a context is SGMX_ERR_RANGE."""
+    rng = np.random.default_rng(5)
+    h, w, D = 18, 70, 32
+    C = (rng.random((h, w, D), dtype=np.float32) * 4).astype(np.float32)
+    C[:, np.arange(D)[None, :] > np.arange(w)[:, None]] = np.finfo(np.float32).max
+    e = sv.SGM(sv.SGMParams(disp_range=D, penalty1=100, penalty2=20000))
+    got = e.compute_cost(C)
+    want = oracle.sgm_cost_f32(C, 100, 20000, 8, taps=True)
+    assert int((got != want["disp"]).sum()) <= 9 * want["n_undefined"]
+    e.close()
+    c = sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=5, penalty1=100, penalty2=20000))
+    with pytest.raises(sv.SgmxError) as ei:
+        c.compute(np.zeros((20, 40), np.uint8), np.zeros((20, 40), np.uint8))
+    assert ei.value.code == 2
+    c.close()
+
+
+def test_wide_image_beyond_the_wta_lds_tables_is_invalid_arg():
+    """check_size prices the WTA kernel's LDS with the formula the launch uses: D = 512 (16 packed pairs per lane:
+    16 KiB tile) leaves room for 9 216 columns, not the 9 728 of narrow ranges."""
+    e = sv.StereoSGM(sv.StereoSGMParams(disp_range=512, window_sz=1, penalty1=3, penalty2=60))
+    img = np.zeros((2, 9300), np.uint8)
+    with pytest.raises(sv.SgmxError) as ei:
+        e.compute(img, img)
+    assert ei.value.code == 1 and "LDS" in str(ei.value)
+    ok = np.zeros((2, 9200), np.uint8)
+    assert e.compute(ok, ok).shape == (2, 9200)
+    e.close()
+
+
+def test_dev_calls_on_two_streams_share_one_context(oracle):
+    """Two _dev calls on different non-blocking streams through one context: the second waits for the first's
+    launch group (shared scratch) instead of overwriting its volumes."""
+    import torch
+    H, W = 60, 200
+    a = synth_pair(901, H, W, 40)
+    b = synth_pair(902, H, W, 40)
+    e = make(disp_range=64, window_sz=5, max_batch=1)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ins = [torch.from_numpy(np.stack(x)).cuda() for x in (a, b)]
+    outs = [torch.zeros((H, W), dtype=torch.int16, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        e.compute_device(ins[0][0].data_ptr(), ins[0][1].data_ptr(), outs[0].data_ptr(), 1, W, H, s1.cuda_stream)
+        e.compute_device(ins[1][0].data_ptr(), ins[1][1].data_ptr(), outs[1].data_ptr(), 1, W, H, s2.cuda_stream)
+    torch.cuda.synchronize()
+    for (l, r), o in zip((a, b), outs):
+        assert np.array_equal(o.cpu().numpy().view(np.uint16), oracle.sgm_census(l, r, 64, 5, 3, 60, 8))
+
+
+@pytest.mark.parametrize("ncodes,ht", [(4, 10), (8, 24), (16, 52), (5, 14)])
+def test_hamming_allocating_and_threaded_forms(oracle, ncodes, ht):
+    """match_hamming_thres, crossmatch_hamming, compute_hamming_thread, match_hamming_thres_nt (core/hamming.h:84-96,
+    108-112) through the C ABI against the restatement and, when built, against the reference's own core/hamming.c."""
+    rng = np.random.default_rng(ncodes * 7 + ht)
+    a = rng.integers(0, 256, size=(300, ncodes)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(270, ncodes)).astype(np.uint8)
+    e = make(disp_range=16)
+    for cross in (False, True):
+        want = oracle.match_hamming(a, b, ht, cross)
+        got = e.crossmatch_hamming_alloc(a, ht, bufsize=3) if cross else e.match_hamming_thres_alloc(a, b, ht, bufsize=3)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        ref = oracle.ref_match_hamming_alloc(a, b, ht, cross, bufsize=3)
+        if ref is not None:
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(e.hamming_matrix_thread(a, b), oracle.hamming_matrix(a, b))
+    k, h = e.match_hamming_thres_nt(a, b, ht)
+    wk, wh = oracle.match_hamming_blocked(a, b, ht)
+    assert len(h) > 0 and np.array_equal(k, wk) and np.array_equal(h, wh)
+    ref = oracle.ref_match_hamming_thres_nt(a, b, ht)
+    if ref is not None:
+        assert np.array_equal(k, ref[0]) and np.array_equal(h, ref[1])
+    # no match at all, and the shapes whose block arithmetic leaves the sets in the reference
+    k0, h0 = e.match_hamming_thres_nt(a[:5], 255 - a[:5], 0)
+    assert k0.shape == (0, 2) and h0.shape == (0,)
+    with pytest.raises(sv.SgmxError):
+        e.match_hamming_thres_nt(a, b[:100], ht)
+    e.close()
+
+
+def test_hamming_compat_library_is_a_drop_in_for_core_hamming(oracle):
+    """libhamming_sgmx.so (include/sgmx_hamming_compat.h) exports core/hamming.h's own names and signatures; the same
+    ctypes prototypes bound to it and to the reference's core/hamming.c build give the same results."""
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_path = os.path.join(root, "oracle", "_ref", "libhamming_ref.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref/libhamming_ref.so not built (reference tree not mounted)")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+    def bind(path):
+        L = C.CDLL(path)
+        L.hamming.argtypes, L.hamming.restype = [u8p, u8p, C.c_int], C.c_uint16
+        L.compute_hamming.argtypes, L.compute_hamming.restype = [C.c_void_p, u8p, u8p, C.c_int, C.c_int, C.c_int], None
+        L.match_hamming_count.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.match_hamming_count.restype = None
+        L.match_hamming_thres_prealloc.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.match_hamming_thres_prealloc.restype = C.c_size_t
+        L.crossmatch_hamming_count.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.crossmatch_hamming_count.restype = None
+        L.crossmatch_hamming_prealloc.argtypes = [u8p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.crossmatch_hamming_prealloc.restype = C.c_size_t
+        return L
+
+    def drive(L, a, b, ht):
+        out = [int(L.hamming(a[3:4].copy(), b[5:6].copy(), a.shape[1]))]
+        dis = np.empty((b.shape[0], a.shape[0]), np.uint16)
+        L.compute_hamming(dis.ctypes.data, a, b, a.shape[0], b.shape[0], a.shape[1])
+        n = C.c_size_t(0)
+        L.match_hamming_count(a, b, a.shape[0], b.shape[0], ht, a.shape[1], C.byref(n))
+        idx, hams = np.zeros((n.value, 2), np.int32), np.zeros(n.value, np.uint16)
+        assert L.match_hamming_thres_prealloc(a, b, a.shape[0], b.shape[0], ht, a.shape[1], idx.ctypes.data, hams.ctypes.data) == n.value
+        m = C.c_size_t(0)
+        L.crossmatch_hamming_count(a, a.shape[0], ht, a.shape[1], C.byref(m))
+        cidx, chams = np.zeros((m.value, 2), np.int32), np.zeros(m.value, np.uint16)
+        assert L.crossmatch_hamming_prealloc(a, a.shape[0], ht, a.shape[1], cidx.ctypes.data, chams.ctypes.data) == m.value
+        return out + [dis, idx, hams, cidx, chams]
+
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 256, size=(90, 8)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(70, 8)).astype(np.uint8)
+    mine = drive(bind(os.path.join(root, "stereo_vision_amd", "libhamming_sgmx.so")), a, b, 26)
+    ref = drive(bind(ref_path), a, b, 26)
+    assert mine[0] == ref[0] and len(mine[3]) > 0 and len(mine[5]) > 0
+    for x, y in zip(mine[1:], ref[1:]):
+        assert np.array_equal(x, y)
