@@ -114,6 +114,23 @@ SGMX_API int sgmx_host_free(sgmx_ctx *ctx, void *ptr);
 SGMX_API int sgmx_compute_census_u8_dev(sgmx_ctx *ctx, int n, const uint8_t *d_left, const uint8_t *d_right, int W,
                                         int H, uint16_t *d_disp, void *stream);
 
+/* sgmx_compute_census_u8_dev for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that must not reach hipMalloc / hipFree -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same arguments, same kernels and bit-identical results, but every
+ * intermediate buffer (census images, the byte volumes of the directions, border rings, the pre-median image)
+ * is a slice of one static 64 MiB __device__ array per GPU (sgmx_noalloc_scratch_bytes()) instead of the
+ * context's scratch, no event is created, and nothing is allocated or freed on this path (sgmx_create, which
+ * looks the array's address up once per device, is not part of it).
+ * Limits: the volume-free formulation only (penalty2 <= 255, no SGMX_FLAG_MATERIALIZE), WTA row tables within
+ * 64 KiB (width up to ~3 900), and one pair's buffers must fit the array -- e.g. 384x288 at D=16, 4 or 8 paths
+ * (3 / 6 MB), 640x480 at D=64, 8 paths (160 MB: too large -> SGMX_ERR_INVALID_ARG with the byte count; use
+ * sgmx_compute_census_u8_dev).  n pairs run in launch groups of as many pairs as fit (at most max_batch).
+ * All calls on one GPU share that GPU's array, whatever the context: calls that overlap in time on one GPU
+ * race; the array keeps the previous call's bytes and the call clears what must start at zero. */
+SGMX_API int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *ctx, int n, const uint8_t *d_left, const uint8_t *d_right, int W,
+                                                int H, uint16_t *d_disp, void *stream);
+SGMX_API size_t sgmx_noalloc_scratch_bytes(void);
+
 /* Float data-cost SGM; replaces the part of
  * cv::Mat recon::SGM::Compute(const std::string, const std::string) (sgm.h:65,
  * sgm.cc:14-174) that follows the data-cost loop: `cost` is the [H][W][D] float

@@ -29,6 +29,8 @@ SYMBOLS = {
     "sgmx_compute_census_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i]),
     "sgmx_compute_census_u8_batch": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "sgmx_compute_census_u8_dev": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "sgmx_compute_census_u8_dev_noalloc": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "sgmx_noalloc_scratch_bytes": (C.c_size_t, []),
     "sgmx_compute_cost_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sgmx_compute_cost_f32_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "sgmx_compute_desc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -49,6 +49,39 @@ struct FastView {
 
 } // namespace
 
+// Scratch of the entry point that allocates nothing (sgmx_compute_census_u8_dev_noalloc): one array per GPU,
+// part of the code object, held by every device the library runs on until the process ends.  In host code this
+// name is only a handle for hipGetSymbolAddress -- never a device address; the per-device addresses live in
+// g_scratch_ptr.
+#define SGMX_NOALLOC_SCRATCH_BYTES ((size_t)64 << 20)
+static __device__ __align__(256) unsigned char sgmx_noalloc_scratch[SGMX_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[MAX_DEVICES] = {nullptr};
+
+// Address of this device's copy of the static scratch; looked up once per device, with that device current.
+hipError_t noalloc_scratch_for_device(int device, unsigned char **out)
+{
+    if (device < 0 || device >= MAX_DEVICES)
+        return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess)
+            return e;
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(sgmx_noalloc_scratch));
+        if (e != hipSuccess)
+            return e;
+        g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+} // namespace
+
 struct sgmx_ctx {
     sgmx_params prm;
     int R = 1;  // packed uint16 pairs per lane (census) / float pairs per lane (float path)
@@ -63,6 +96,7 @@ struct sgmx_ctx {
     int RP = 4, DpF = 128;     // fast path: packed pairs per lane, padded disparity count 32 * RP
     int wp = 0;                // row pitch of the padded right census image (fast path)
     int last_n = 0;            // pairs in the last launch group
+    unsigned char *noalloc_scratch = nullptr; // this device's copy of sgmx_noalloc_scratch
     // The scratch below is shared by every call on this context.  ev_scratch is recorded behind the last
     // launch group; a call on another stream waits for it before it touches the scratch.
     hipEvent_t ev_scratch = nullptr;
@@ -714,7 +748,7 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "num_paths must be 4 or 8");
     if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 || (p.flags & ~SGMX_FLAG_MATERIALIZE) != 0)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "negative penalty, bad max_batch or unknown flags");
-    if (p.device < 0 || p.device >= 64)
+    if (p.device < 0 || p.device >= MAX_DEVICES)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "device ordinal out of range");
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
@@ -735,14 +769,16 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->DpF = 32 * c->RP;
     bool ok = hipSetDevice(p.device) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess &&
               hipStreamCreate(&c->copy_stream) == hipSuccess &&
-              hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) == hipSuccess &&
+              // set-up of the entry point that allocates nothing: this device's address of the static scratch
+              noalloc_scratch_for_device(p.device, &c->noalloc_scratch) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++)
         ok = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         sgmx_destroy(c);
-        return fail(nullptr, SGMX_ERR_HIP, "hipSetDevice / stream or event creation failed");
+        return fail(nullptr, SGMX_ERR_HIP, "hipSetDevice / stream or event creation / hipGetSymbolAddress failed");
     }
     *out = c;
     return SGMX_OK;
@@ -789,6 +825,75 @@ int sgmx_compute_census_u8_dev(sgmx_ctx *c, int n, const uint8_t *d_left, const 
     for (int i = 0; i < n; i += c->prm.max_batch) {
         const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
         rc = census_group(c, g, d_left + i * nfull, d_right + i * nfull, d_disp + i * nfull, st);
+        if (rc)
+            return rc;
+    }
+    return SGMX_OK;
+}
+
+size_t sgmx_noalloc_scratch_bytes(void) { return SGMX_NOALLOC_SCRATCH_BYTES; }
+
+// sgmx_compute_census_u8_dev for callers that cannot allocate: same kernels, but every intermediate buffer is a
+// slice of this device's static scratch array instead of the context's hipMalloc'd scratch, and no event is
+// created.  No hipMalloc / hipFree / allocating routine is called on this path.
+int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *c, int n, const uint8_t *d_left, const uint8_t *d_right, int W, int H,
+                                       uint16_t *d_disp, void *stream)
+{
+    if (!c || !d_left || !d_right || !d_disp || n < 1)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or n < 1");
+    int rc = check_size(c, W, H, true);
+    if (rc)
+        return rc;
+    if (!c->fast)
+        return fail(c, SGMX_ERR_INVALID_ARG, "the no-allocation entry point serves the volume-free formulation only "
+                                             "(penalty2 <= 255, no SGMX_FLAG_MATERIALIZE)");
+    const int m = (c->prm.window_sz - 1) / 2, w = W - 2 * m, h = H - 2 * m, wp = w + c->DpF;
+    const size_t lds = wta3_lds_bytes(c->DpF, w);
+    if (lds > 64 * 1024)
+        return fail(c, SGMX_ERR_INVALID_ARG, "image too wide for the no-allocation entry point (WTA tables above 64 KiB "
+                                             "would need a function attribute change)");
+    // layout of one launch group of g pairs in the scratch, every part 256-byte aligned
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t npix = (size_t)w * h, nfull = (size_t)W * H;
+    const size_t b_cl = up(npix * 4), b_cr = up((size_t)wp * h * 4), b_E = npix * c->DpF /* multiple of 32 */,
+                 b_ring = (size_t)(2 * w + 2 * h) * c->DpF * 2, b_raw = up(nfull * 2);
+    const int np = c->prm.num_paths;
+    auto need = [&](size_t g) { return g * (b_cl + b_cr + b_raw) + up(g * b_E) * np + 2 * up(g * b_ring); };
+    if (need(1) > SGMX_NOALLOC_SCRATCH_BYTES)
+        return fail(c, SGMX_ERR_INVALID_ARG,
+                    "one pair needs " + std::to_string(need(1)) + " bytes of scratch; the no-allocation entry point has " +
+                        std::to_string(SGMX_NOALLOC_SCRATCH_BYTES) + " (use sgmx_compute_census_u8_dev)");
+    int g = n < c->prm.max_batch ? n : c->prm.max_batch;
+    while (need((size_t)g) > SGMX_NOALLOC_SCRATCH_BYTES)
+        g--;
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    unsigned char *base = c->noalloc_scratch; // hipGetSymbolAddress result of this device (sgmx_create)
+    if (!base)
+        return fail(c, SGMX_ERR_STATE, "static scratch address missing");
+    FastView v;
+    v.W = W; v.H = H; v.w = w; v.h = h; v.m = m; v.wp = wp;
+    v.cap = g;
+    v.bytes_E = b_E;
+    v.bytes_BL = b_ring;
+    size_t off = 0;
+    v.cl = reinterpret_cast<u32 *>(base + off); off += (size_t)g * b_cl;
+    v.cr = reinterpret_cast<u32 *>(base + off); off += (size_t)g * b_cr;
+    v.raw = reinterpret_cast<uint16_t *>(base + off); off += (size_t)g * b_raw;
+    v.E = base + off; off += up((size_t)g * b_E) * np;
+    v.BL = reinterpret_cast<uint16_t *>(base + off); off += up((size_t)g * b_ring);
+    v.SB = reinterpret_cast<uint16_t *>(base + off); off += up((size_t)g * b_ring);
+    // pairs of a group lie back to back at the unpadded sizes the kernels index with; the rounded-up
+    // parts above only reserve room, so recompute the real extents for the clears
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n; i += g) {
+        const int k = n - i < g ? n - i : g;
+        // The array keeps the previous call's bytes: clear what must start at zero -- the padding columns of the
+        // right census image, the zero border of the disparity image (the rings are cleared in run_fast).
+        HIPCHK(c, hipMemsetAsync(v.cr, 0, (size_t)k * wp * h * 4, st));
+        HIPCHK(c, hipMemsetAsync(v.raw, 0, (size_t)k * nfull * 2, st));
+        rc = run_census(c, k, d_left + (size_t)i * nfull, d_right + (size_t)i * nfull, W, H, v.cl, v.cr, wp, c->DpF, st, false);
+        if (!rc)
+            rc = run_fast(c, v, k, d_disp + (size_t)i * nfull, st, false);
         if (rc)
             return rc;
     }

@@ -147,6 +147,11 @@ class StereoSGM(Engine):
         """Device-resident batch: raw device pointers (ints), enqueue only."""
         self.check(self.lib.sgmx_compute_census_u8_dev(self.h, n, d_left, d_right, W, H, d_disp, stream))
 
+    def compute_device_noalloc(self, d_left, d_right, d_disp, n, W, H, stream=0):
+        """The same through the entry point that allocates nothing (static per-GPU scratch, size limits:
+        include/sgmx.h)."""
+        self.check(self.lib.sgmx_compute_census_u8_dev_noalloc(self.h, n, d_left, d_right, W, H, d_disp, stream))
+
     # ---- stage taps ----
     def census(self, img):
         img = np.ascontiguousarray(img, np.uint8)
