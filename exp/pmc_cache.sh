@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1)); out=gpurun_out/pmcc_$1_$i
-  timeout -s KILL 90 rocprofv3 --pmc $set --output-format csv -d $out -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-events $EXTRA > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+  timeout -s KILL 90 rocprofv3 --pmc $set --output-format csv -d $out -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-events --no-secondary $EXTRA > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$out/*/*counter_collection.csv')[0]

@@ -2,7 +2,7 @@
 # usage: [EXTRA="--batch 1"] exp/pmc_one.sh TAG "COUNTERS" -- one PMC pass over one bench step, per-launch values of the last launch group
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc1_$1
-timeout -s KILL 90 rocprofv3 --pmc $2 --output-format csv -d $out -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-events $EXTRA > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+timeout -s KILL 90 rocprofv3 --pmc $2 --output-format csv -d $out -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-events --no-secondary $EXTRA > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$out/*/*counter_collection.csv')[0]

@@ -2,7 +2,7 @@
 # usage: [EXTRA="--width 3840 ..."] exp/pmc_valu.sh TAG  -- one PMC pass of SQ instruction / cycle counters over one bench step
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc_$1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-events $EXTRA > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-events --no-secondary $EXTRA > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$out/*/*counter_collection.csv')[0]

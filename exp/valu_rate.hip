@@ -82,6 +82,9 @@ template <int OP> __global__ __launch_bounds__(1024) void k(u32 *out, u64 *stamp
             else if (OP == 37) asm volatile("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));
             else if (OP == 38) asm volatile("v_sad_u8 %0, %1, %2, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));
             else if (OP == 39) asm volatile("v_mad_u32_u24 %0, %1, %2, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));
+            else if (OP == 40) asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));
+            else if (OP == 41) asm volatile("v_not_b32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            else if (OP == 42) asm volatile("v_pk_max_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(a[i]) : "v"(a[i]));
         }
     }
     const u64 t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -152,6 +155,8 @@ int main()
            p.gcnArchName, g_cus);
     int rc = 0;
     rc |= run<0>("v_xor_b32");
+    rc |= run<40>("v_xnor_b32");
+    rc |= run<41>("v_not_b32");
     rc |= run<10>("v_add_u32");
     rc |= run<11>("v_min_u32");
     rc |= run<14>("v_mov_b32");
@@ -162,6 +167,7 @@ int main()
     rc |= run<3>("v_pk_add_u16");
     rc |= run<12>("v_pk_sub_u16");
     rc |= run<13>("v_pk_max_u16");
+    rc |= run<42>("v_pk_max_u16 op_sel swap");
     rc |= run<4>("v_min_u32_dpp row_ror:1");
     rc |= run<5>("v_mov_b32_dpp row_shr:1");
     rc |= run<6>("v_lshl_add_u32");

@@ -96,6 +96,7 @@ struct sgmx_ctx {
     int RP = 4, DpF = 128;     // fast path: packed pairs per lane, padded disparity count 32 * RP
     int wp = 0;                // row pitch of the padded right census image (fast path)
     int last_n = 0;            // pairs in the last launch group
+    int num_cus = 256;
     unsigned char *noalloc_scratch = nullptr; // this device's copy of sgmx_noalloc_scratch
     // The scratch below is shared by every call on this context.  ev_scratch is recorded behind the last
     // launch group; a call on another stream waits for it before it touches the scratch.
@@ -387,8 +388,9 @@ int run_wta_median(sgmx_ctx *c, int n, bool f32, uint16_t *d_disp, hipStream_t s
     return SGMX_OK;
 }
 
-template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
-                                   uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a)
+// lds: dynamic LDS of the launch (the staged variants); above 64 KiB the function attribute has to allow it.
+template <int RP> hipError_t launch_agg3(bool first, bool pad, dim3 grid, hipStream_t st, const u32 *cl, const u32 *cr,
+                                         uint8_t *E, uint16_t *BL, uint16_t *SB, const Agg2Args &a, size_t lds)
 {
 #ifndef SGMX_PF
 #define SGMX_PF 4
@@ -397,17 +399,18 @@ template <int RP> void launch_agg3(bool first, bool pad, dim3 grid, hipStream_t 
 #define SGMX_PF8 2
 #endif
     constexpr int PF = RP >= 12 ? 2 : (RP == 8 ? SGMX_PF8 : SGMX_PF); // census prefetch depth in steps (2, 3, 6, 8 measured slower at RP = 4)
-    if (first) {
-        if (pad)
-            hipLaunchKernelGGL((aggregate3_kernel<RP, true, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
-        else
-            hipLaunchKernelGGL((aggregate3_kernel<RP, true, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
-    } else {
-        if (pad)
-            hipLaunchKernelGGL((aggregate3_kernel<RP, false, true, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
-        else
-            hipLaunchKernelGGL((aggregate3_kernel<RP, false, false, PF>), grid, dim3(256), 0, st, cl, cr, E, BL, SB, a);
-    }
+    auto go = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, cl, cr, E, BL, SB, a);
+        return hipSuccess;
+    };
+    if (first)
+        return pad ? go(aggregate3_kernel<RP, true, true, PF>) : go(aggregate3_kernel<RP, true, false, PF>);
+    return pad ? go(aggregate3_kernel<RP, false, true, PF>) : go(aggregate3_kernel<RP, false, false, PF>);
 }
 
 SumArgs sum_args(const sgmx_ctx *c, const FastView &v)
@@ -423,6 +426,7 @@ SumArgs sum_args(const sgmx_ctx *c, const FastView &v)
     a.D = c->prm.disp_range;
     a.wp = v.wp;
     a.N = c->prm.num_paths;
+    a.P2 = c->prm.penalty2;
     return a;
 }
 
@@ -470,21 +474,25 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
         a.P2 = c->prm.penalty2;
         a.npaths = a.dy == 0 ? v.h : (a.dx == 0 ? v.w : v.w + v.h - 1);
         a.npairs = n;
-        const dim3 grid(8 * ((((a.npaths + 15) / 16) * n + 7) / 8)); // 4 waves x 4 paths per workgroup, 8 equal XCD chunks
+        const int nwg = ((a.npaths + 15) / 16) * n; // 4 waves x 4 paths per workgroup
+        const dim3 grid(8 * ((nwg + 7) / 8));       // 8 equal XCD chunks
+        const size_t lds = 0;
         uint8_t *Ek = v.E + (size_t)k * v.bytes_E * v.cap;
         ProfScope ps(c, SGMX_K_AGGREGATE, st);
+        hipError_t le;
         if (c->RP == 1)
-            launch_agg3<1>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
+            le = launch_agg3<1>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
         else if (c->RP == 2)
-            launch_agg3<2>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
+            le = launch_agg3<2>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
         else if (c->RP == 4)
-            launch_agg3<4>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
+            le = launch_agg3<4>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
         else if (c->RP == 8)
-            launch_agg3<8>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
+            le = launch_agg3<8>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
         else if (c->RP == 12)
-            launch_agg3<12>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
+            le = launch_agg3<12>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
         else
-            launch_agg3<16>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a);
+            le = launch_agg3<16>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
+        HIPCHK(c, le);
         HIPCHK(c, hipGetLastError());
     }
     {
@@ -776,6 +784,9 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
         ok = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming) == hipSuccess;
+    int cus = 0;
+    if (ok && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) == hipSuccess && cus > 0)
+        c->num_cus = cus;
     if (!ok) {
         sgmx_destroy(c);
         return fail(nullptr, SGMX_ERR_HIP, "hipSetDevice / stream or event creation / hipGetSymbolAddress failed");

@@ -44,7 +44,10 @@ namespace sgmx {
 
 // E bytes are written once and read once, a whole launch later: non-temporal stores (aux bit 1 = nt)
 // keep them from evicting the census images out of L2 (measured: 0.84 -> 0.60 ms per sweep).
-constexpr int E_STORE_AUX = 2; // cache policy bits of a buffer store: 2 = nt
+#ifndef SGMX_E_AUX
+#define SGMX_E_AUX 2
+#endif
+constexpr int E_STORE_AUX = SGMX_E_AUX; // cache policy bits of a buffer store: 2 = nt
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -66,6 +69,38 @@ __device__ __forceinline__ u32 row_min_u32(u32 x)
     x = min(x, dpp<0x124>(0xFFFFFFFFu, x));
     x = min(x, dpp<0x128>(0xFFFFFFFFu, x));
     return x;
+}
+
+// Maximum over the 16 lanes of a row, left in every lane (0 is the identity of umax: v_max_u32_dpp).
+__device__ __forceinline__ u32 row_max_u32(u32 x)
+{
+    x = max(x, dpp<0x121>(0u, x));
+    x = max(x, dpp<0x122>(0u, x));
+    x = max(x, dpp<0x124>(0u, x));
+    x = max(x, dpp<0x128>(0u, x));
+    return x;
+}
+
+// max(a - b, 0) on both halves (v_pk_sub_u16 ... clamp)
+__device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+// Three-input packed uint16 maximum.  gfx950 has no integer form; v_pk_maximum3_f16 is exact on halves below
+// 0x7C00 (positive finite f16 patterns order like the integers, denormals included: exp/pkmax3_check.hip,
+// profiles/r02_valu_issue.txt).  Every caller's values are path-cost terms far below that.
+__device__ __forceinline__ u32 pk_max3(u32 a, u32 b, u32 c)
+{
+    u32 r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (max(lo, hi), max(lo, hi)): src1 enters with its halves swapped, one instruction
+__device__ __forceinline__ u32 pk_max_halves(u32 a)
+{
+    u32 r;
+    asm("v_pk_max_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+    return r;
 }
 
 // RP consecutive census words through a buffer descriptor (4-byte aligned)
@@ -264,10 +299,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     const u32 P1p = (u32)a.P1 * 0x10001u, P2p = (u32)a.P2 * 0x10001u;
     const int tl0 = g.x0 - RP * q;          // x - RP q at step 0
     const int th0 = Dp - 1 - RP * q - g.x0; // Dp-1 - RP q - x at step 0
-    u32 padfloor[RP];
+    u32 padfloor[RP], padmask[RP];
 #pragma unroll
-    for (int j = 0; j < RP; j++)
+    for (int j = 0; j < RP; j++) {
         padfloor[j] = (RP * q + j >= a.D ? INF16 : 0u) | (Dp - 1 - (RP * q + j) >= a.D ? INF16 << 16 : 0u);
+        padmask[j] = (RP * q + j >= a.D ? 0u : 0xFFFFu) | (Dp - 1 - (RP * q + j) >= a.D ? 0u : 0xFFFF0000u);
+    }
+    // The state carried from pixel to pixel is not L but Q = K - L for a constant K (bigger is better; pad and
+    // far-away disparities sit at 0).  aggregate_path only looks at differences of the previous pixel's costs,
+    // so K may change from step to step; what every producer of Q guarantees is max_d Q >= P2.
+    //   unmasked steady state: Q = (P2 - E) + (32 - C)          (K = 32 + P2; 32 - C is a popcount too)
+    //   steps with d > x costs / last steps:  Q = KM - L         (KM = 255 + 2 P2 >= every L there, + P2)
+    //   start pixels:                         Q = sat(KS - L)    (KS = 0x7000 > every start value; pads -> 0)
+    const u32 KMp = (u32)(255 + 2 * a.P2) * 0x10001u, K32p = (u32)(32 + a.P2) * 0x10001u;
 
     // ---- step 0, the start pixels: L_k = L_{k-1} + C; their E bytes are 0, the carry goes to SB
     u32 prior[RP];
@@ -299,13 +343,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             if (HAS_PAD)
                 prior[j] = pk_max(prior[j], padfloor[j]);
         }
-        u32 zero[NW];
+        // the byte volumes hold G = P2 - E (what the steps compute): E = 0 on start pixels
+        u32 gstart[NW];
 #pragma unroll
         for (int m = 0; m < NW; m++)
-            zero[m] = 0u;
-        buf_store_ev<RP>(rsE, voE, soE0, zero);
+            gstart[m] = (u32)a.P2 * 0x01010101u;
+        buf_store_ev<RP>(rsE, voE, soE0, gstart);
         if (valid)
             __builtin_memcpy(BLf + bo, prior, 4 * RP);
+#pragma unroll
+        for (int j = 0; j < RP; j++)
+            prior[j] = pk_sub_sat(0x70007000u, prior[j]); // L -> Q (pads: INF16 -> 0)
     }
     if (maxlen == 1)
         return;
@@ -320,7 +368,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0 + (1 + i) * sL, 0);
         }
     u32 *bl_last = BLf + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
-    u32 below = INF2; // "register -1": lanes 1..15 get it from lane q-1 every step, lane 0 keeps the INF pair
 
     unsigned soRp = soR0 + (1 + PF) * sR, soLp = soL0 + (1 + PF) * sL; // soffsets of the step PF ahead
     unsigned soE = soE0, soB = soB0;
@@ -336,7 +383,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         }
         const u32 clv = qcl[i];
         auto prefetch = [&]() { // census words PF steps ahead, into the ring slot this step has just consumed
+#ifdef SGMX_EXP_NOLOAD // timing-only build (wrong results): the steady-state loops without their census loads
+            if (SLOW && t + PF < len) {
+#else
             if (!SLOW || t + PF < len) { // (fast blocks: in range for every row)
+#endif
                 buf_load_win<RP>(rsR, voRl, soRp, qwl[i]);
                 buf_load_win<RP>(rsR, voRh, soRp, qwh[i]);
                 qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
@@ -347,42 +398,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         if (SLOW)
             prefetch();
         constexpr bool MASK = decltype(maskc)::value;
-        // stereo_sgm.h:129-146 in the mirrored layout (see the head of this file)
-        below = dpp<0x111>(below, prior[RP - 1]);                                                             // row_shr:1
-        const u32 above = dpp<0x101>(__builtin_amdgcn_alignbit(prior[RP - 1], prior[RP - 1], 16), prior[0]); // row_shl:1
-        u32 mn = prior[0];
+        // stereo_sgm.h:129-146 in the mirrored layout (see the head of this file), on Q = K - L:
+        //   G = P2 - E = max(P2 - (L[d] - m), P2 - P1 - (L[d+-1] - m), 0)
+        //     = max(g[d], h[d-1], h[d+1])  with  g = sat(Q - (maxQ - P2)),  h = sat(g - P1)
+        // (saturating subtractions do the clamping at 0 = "P2 or more above the minimum").
+        u32 mx = prior[0];
 #pragma unroll
-        for (int j = 1; j < RP; j++)
-            mn = pk_min(mn, prior[j]);
-        const u32 mp = row_min_u32(pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16))); // (m, m)
-        u32 e[RP];
+        for (int j = 1; j + 1 < RP; j += 2)
+            mx = pk_max3(mx, prior[j], prior[j + 1]);
+        if constexpr (RP % 2 == 0)
+            mx = pk_max(mx, prior[RP - 1]);
+        const u32 mq = row_max_u32(pk_max_halves(mx));      // (max Q, max Q) in every lane of the row
+        const u32 tq = pk_sub(mq, P2p);                      // >= 0: every producer of Q keeps max Q >= P2
+        u32 gq[RP], hh[RP];
 #pragma unroll
         for (int j = 0; j < RP; j++) {
-            const u32 prev = j ? prior[j - 1] : below;
-            const u32 next = j < RP - 1 ? prior[j + 1] : above;
-            const u32 A = pk_min(prior[j], pk_add(pk_min(prev, next), P1p));
-            e[j] = pk_min(pk_sub(A, mp), P2p);
+            gq[j] = pk_sub_sat(prior[j], tq);
+            hh[j] = pk_sub_sat(gq[j], P1p);
         }
+        // "register -1": lane q-1's top register; lane 0 has no neighbour on either half -> 0 (bound_ctrl)
+        const u32 hbelow = (u32)__builtin_amdgcn_update_dpp(0, (int)hh[RP - 1], 0x111, 0xF, 0xF, true);   // row_shr:1
+        // "register RP": lane q+1's register 0; lane 15 keeps its own top register with the halves swapped
+        const u32 habove = dpp<0x101>(__builtin_amdgcn_alignbit(hh[RP - 1], hh[RP - 1], 16), hh[0]);      // row_shl:1
+        u32 e[RP]; // G = P2 - E
+#pragma unroll
+        for (int j = 0; j < RP; j++)
+            e[j] = pk_max3(gq[j], j ? hh[j - 1] : hbelow, j < RP - 1 ? hh[j + 1] : habove);
+        u32 Lv[RP] = {}; // the true path costs, where a ring store may need them
         if (MASK) {
             u32 c[RP];
             cost_from_census<RP, true>(wl, wh, clv, tl0 + t * a.dx, th0 - t * a.dx, c);
 #pragma unroll
-            for (int j = 0; j < RP; j++)
-                prior[j] = pk_add(e[j], c[j]);
+            for (int j = 0; j < RP; j++) {
+                Lv[j] = pk_add(pk_sub(P2p, e[j]), c[j]);
+                if (HAS_PAD)
+                    Lv[j] = pk_max(Lv[j], padfloor[j]);
+                prior[j] = pk_sub_sat(KMp, Lv[j]);
+            }
         } else {
-            // L = E + C with the adds folded into the popcounts (v_bcnt accumulates) and the half merge
+            // Q = G + (32 - C): 32 - popcount(x) = popcount(~x), the add folded into the popcount (v_bcnt
+            // accumulates) and into the merge of the halves
+            // (through asm: left to itself the compiler fuses the complement into eight v_xnor_b32, which issue at
+            //  half the rate of v_xor_b32 -- profiles/r02_valu_issue.txt)
+            u32 ncl;
+            asm("v_not_b32 %0, %1" : "=v"(ncl) : "v"(clv));
 #pragma unroll
             for (int j = 0; j < RP; j++) {
                 u32 lo, hi;
-                asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(lo) : "v"(wl[RP - 1 - j] ^ clv), "v"(e[j])); // popcount + E pair
-                asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(hi) : "v"(wh[j] ^ clv));
+                asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(lo) : "v"(wl[RP - 1 - j] ^ ncl), "v"(e[j]));
+                asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(hi) : "v"(wh[j] ^ ncl));
                 asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(prior[j]) : "v"(hi), "v"(lo));
+                if (HAS_PAD)
+                    prior[j] &= padmask[j];
+                if (EDGE)
+                    Lv[j] = pk_sub(K32p, prior[j]);
             }
         }
-#pragma unroll
-        for (int j = 0; j < RP; j++)
-            if (HAS_PAD)
-                prior[j] = pk_max(prior[j], padfloor[j]);
         if (!SLOW) {
             // after the slot's last use, and not hoisted above it: otherwise the compiler copies the slot
             __builtin_amdgcn_sched_barrier(0);
@@ -391,19 +462,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         u32 eb[NW];
         pack_e<RP>(e, eb);
         if (!SLOW) {
+#ifndef SGMX_EXP_NOSTORE // (defined: timing-only build, wrong results, the steady-state loops without their E stores)
             buf_store_ev<RP>(rsE, voE, soE, eb);
+#else
+            if (a.npairs < 0) // keeps eb alive
+                buf_store_ev<RP>(rsE, voE, soE, eb);
+#endif
             if (EDGE && edge_store) {
                 if constexpr (RP == 1) {
-                    __builtin_amdgcn_raw_buffer_store_b32(prior[0], rsB, voB, soB, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(Lv[0], rsB, voB, soB, 0);
                 } else if constexpr (RP == 2) {
                     u32x2 v;
-                    v.x = prior[0]; v.y = prior[1];
+                    v.x = Lv[0]; v.y = Lv[1];
                     __builtin_amdgcn_raw_buffer_store_b64(v, rsB, voB, soB, 0);
                 } else {
 #pragma unroll
                     for (int m = 0; m < RP / 4; m++) {
                         u32x4 v;
-                        v.x = prior[4 * m]; v.y = prior[4 * m + 1]; v.z = prior[4 * m + 2]; v.w = prior[4 * m + 3];
+                        v.x = Lv[4 * m]; v.y = Lv[4 * m + 1]; v.z = Lv[4 * m + 2]; v.w = Lv[4 * m + 3];
                         __builtin_amdgcn_raw_buffer_store_b128(v, rsB, voB + 16 * m, soB, 0);
                     }
                 }
@@ -412,9 +488,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             buf_store_ev<RP>(rsE, voE, soE, eb);
             if (valid) {
                 if (g.edge) // path along an image edge: every pixel feeds a later direction's start
-                    __builtin_memcpy(BLf + (size_t)border_index(g.y0 + t * a.dy, g.x0 + t * a.dx, w, h) * (Dp / 2), prior, 4 * RP);
+                    __builtin_memcpy(BLf + (size_t)border_index(g.y0 + t * a.dy, g.x0 + t * a.dx, w, h) * (Dp / 2), Lv, 4 * RP);
                 else if (t == len - 1)
-                    __builtin_memcpy(bl_last, prior, 4 * RP);
+                    __builtin_memcpy(bl_last, Lv, 4 * RP);
             }
         }
     };
@@ -463,6 +539,7 @@ struct SumArgs {
     size_t estride; // bytes between the volumes of two directions
     const uint16_t *SB;
     int w, h, D, wp, N;
+    int P2; // the byte volumes hold G = P2 - E
 };
 
 // Raw inputs of one pixel's S for one lane: loaded one iteration ahead of their use.
@@ -505,8 +582,8 @@ __device__ __forceinline__ void load_pixel(const SumArgs &a, int pair, int y, in
         }
 }
 
-// S = N C + sum_k E_k.  The E bytes of G volumes are added as packed bytes first (no carry while
-// G * P2 <= 255), then widened to the packed uint16 pairs.
+// S = N C + sum_k E_k = N (C + P2) - sum_k G_k: the byte volumes hold G = P2 - E.  The bytes of G volumes are
+// added as packed bytes first (no carry while G * P2 <= 255), then widened to the packed uint16 pairs.
 template <int RP, int G, bool MASK>
 __device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &r, int x, int q, u32 (&S)[RP])
 {
@@ -514,9 +591,10 @@ __device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &
     u32 c[RP];
     cost_from_census<RP, MASK>(r.wl, r.wh, r.clv, x - RP * q, 32 * RP - 1 - RP * q - x, c);
     const int sh = a.N == 8 ? 3 : 2;
+    const u32 np2 = (u32)(a.N * a.P2) * 0x10001u;
 #pragma unroll
     for (int j = 0; j < RP; j++)
-        S[j] = c[j] << sh; // N * C
+        S[j] = pk_add(c[j] << sh, np2); // N * (C + P2)
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0 += G)
         if (k0 < a.N) {
@@ -531,7 +609,7 @@ __device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &
                     acc[m] += r.ev[k][m];
 #pragma unroll
             for (int j = 0; j < RP; j++)
-                S[j] = pk_add(S[j], __builtin_amdgcn_perm(0u, acc[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u));
+                S[j] = pk_sub(S[j], __builtin_amdgcn_perm(0u, acc[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u));
         }
 }
 
