@@ -606,6 +606,26 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
     return rc;
 }
 
+// The descriptor data cost of one pair into d_C (pitch Dp): sgm.cc:76-84, or with replicate the variant of
+// new_sgm/sgm_stereo.cc:158-181.
+int run_descriptor_cost(sgmx_ctx *c, bool replicate, const float *d_fl, const float *d_fr, int W, int H, int K, hipStream_t st)
+{
+    const int D = c->prm.disp_range;
+    const size_t lds = desc_lds_bytes(D, c->Dp);
+    const void *fn = replicate ? (const void *)descriptor_cost_kernel<true> : (const void *)descriptor_cost_kernel<false>;
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int TX = desc_tile_pixels(c->Dp);
+    const dim3 grid((W + TX - 1) / TX, H);
+    ProfScope ps(c, SGMX_K_HAMMING, st); // data-cost class
+    if (replicate)
+        hipLaunchKernelGGL(descriptor_cost_kernel<true>, grid, dim3(256), lds, st, d_fl, d_fr, W, K, D, c->Dp, (float *)c->d_C);
+    else
+        hipLaunchKernelGGL(descriptor_cost_kernel<false>, grid, dim3(256), lds, st, d_fl, d_fr, W, K, D, c->Dp, (float *)c->d_C);
+    HIPCHK(c, hipGetLastError());
+    return SGMX_OK;
+}
+
 // SpeckleFilter(100, 2, image) of sgm_stereo.cc:413 on n integer disparity images.
 int ns_speckle(sgmx_ctx *c, int n, int *d_img, hipStream_t st)
 {
@@ -1126,10 +1146,9 @@ int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_f + npix * K, desc_right, nb, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        const size_t tot = npix * c->Dp;
-        hipLaunchKernelGGL(descriptor_cost_kernel<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_f,
-                           d_f + npix * K, W, K, c->prm.disp_range, c->Dp, (float *)c->d_C, tot);
-        rc = run_aggregation(c, 1, true, st, c->d_C);
+        rc = run_descriptor_cost(c, false, d_f, d_f + npix * K, W, H, K, st);
+        if (!rc)
+            rc = run_aggregation(c, 1, true, st, c->d_C);
         if (!rc)
             rc = run_wta_median(c, 1, true, c->d_out, st);
         c->last_n = 1;
@@ -1229,10 +1248,9 @@ int sgmx_sgmstereo_desc_f32(sgmx_ctx *c, const float *desc_left, const float *de
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_f + npix * K, desc_right, nb, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        const size_t tot = npix * c->Dp;
-        hipLaunchKernelGGL(descriptor_cost_kernel<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_f,
-                           d_f + npix * K, W, K, c->prm.disp_range, c->Dp, (float *)c->d_C, tot);
-        rc = ns_group(c, 1, (const float *)c->d_C, consistency_threshold, c->d_out, st);
+        rc = run_descriptor_cost(c, true, d_f, d_f + npix * K, W, H, K, st);
+        if (!rc)
+            rc = ns_group(c, 1, (const float *)c->d_C, consistency_threshold, c->d_out, st);
         if (!rc)
             e = hipMemcpyAsync(disp, c->d_out, npix * 2, hipMemcpyDeviceToHost, st);
     }
