@@ -115,12 +115,19 @@ def secondary_figures(eng, sv, args, Lh, Rh, B, W, H):
             lib.sgmx_host_free(eng.h, p)
     one = sv.StereoSGM(sv.StereoSGMParams(disp_range=args.disp, window_sz=args.wsz, penalty1=args.p1, penalty2=args.p2,
                                           num_paths=args.paths, device=eng.params.device, max_batch=1))
-    one.compute(Lh[0], Rh[0])
-    reps = 20
+    l1, r1 = np.ascontiguousarray(Lh[0]), np.ascontiguousarray(Rh[0])
+    o1 = np.empty((H, W), np.uint16)
+
+    def call():  # the C entry point itself, caller-owned buffers reused from call to call
+        one.check(lib.sgmx_compute_census_u8(one.h, l1.ctypes.data, r1.ctypes.data, W, H, W, W, o1.ctypes.data, 2 * W))
+    for _ in range(3):
+        call()
+    reps = 30
     t0 = time.perf_counter()
     for _ in range(reps):
-        one.compute(Lh[0], Rh[0])
+        call()
     sec["single_pair_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+    sec["single_pair_note"] = "sgmx_compute_census_u8, one pair per call, pageable host buffers in and out"
     one.close()
     return sec
 

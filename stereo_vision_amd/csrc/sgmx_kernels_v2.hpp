@@ -264,6 +264,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         minx = x < minx ? x : minx;
     }
     const bool any_edge = __builtin_amdgcn_readfirstlane((int)(__ballot(g.edge) != 0ull)) != 0;
+    // A wave with a path along an image edge stores L of every pixel into the ring: ~30 % more work per step
+    // than its neighbours on the SIMD, and with every wave of a horizontal sweep resident from the start the
+    // launch lasts as long as those few waves (0.52 ms against 0.42 for the other directions).  They go first.
+#ifndef SGMX_NO_EDGE_PRIO
+    if (any_edge)
+        __builtin_amdgcn_s_setprio(3);
+#endif
 
     // per-step byte strides and stream bases
     const int sRi = (a.dy * wp + a.dx) * 4, sLi = (a.dy * w + a.dx) * 4, sEi = (a.dy * w + a.dx) * Dp;
