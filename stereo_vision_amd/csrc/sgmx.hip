@@ -408,6 +408,19 @@ template <int RP> hipError_t launch_agg3(bool first, bool pad, dim3 grid, hipStr
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, cl, cr, E, BL, SB, a);
         return hipSuccess;
     };
+    // horizontal sweeps: census windows as a shift register across the lanes (aggregate3_kernel, HZ); the first
+    // direction of either schedule is never horizontal
+#ifndef SGMX_HZ
+#define SGMX_HZ 1
+#endif
+    if constexpr (SGMX_HZ && RP <= 8) {
+        constexpr int PFH = RP == 8 ? 8 : 4;
+        if (a.dy == 0 && !first) {
+            if (a.dx > 0)
+                return pad ? go(aggregate3_kernel<RP, false, true, PFH, 1>) : go(aggregate3_kernel<RP, false, false, PFH, 1>);
+            return pad ? go(aggregate3_kernel<RP, false, true, PFH, -1>) : go(aggregate3_kernel<RP, false, false, PFH, -1>);
+        }
+    }
     if (first)
         return pad ? go(aggregate3_kernel<RP, true, true, PF>) : go(aggregate3_kernel<RP, true, false, PF>);
     return pad ? go(aggregate3_kernel<RP, false, true, PF>) : go(aggregate3_kernel<RP, false, false, PF>);

@@ -215,7 +215,13 @@ __device__ __forceinline__ LaneGeom lane_geometry(int p, int w, int h, int dx, i
 // one scalar add.  For a negative stride the walk runs downwards from T|s| (T = longest path - 1)
 // and base' = base - T|s|, so soffset never goes negative; the descriptors are unbounded.
 // ---------------------------------------------------------------------------
-template <int RP, bool FIRST, bool HAS_PAD, int PF>
+// HZ != 0 (horizontal sweeps, dx = HZ = +-1): a path's Dp census words censR[x-Dp+1 .. x] sit in its 16 lanes as
+// one long shift register -- the low windows run down the lanes, the high windows up, and the two meet in lane
+// 15.  Stepping x by one shifts every window by one word: the word a lane gains is the word its neighbour drops
+// (one row_shr and one row_shl DPP move), lane 15 hands its own word from one half to the other, and only lane 0
+// takes a word from memory (a 4-byte broadcast load per path and step instead of 2 x 4 RP bytes per lane).  The
+// shifts inside a lane are register renaming once the loop is unrolled RP steps (PF is a multiple of RP here).
+template <int RP, bool FIRST, bool HAS_PAD, int PF, int HZ = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4 : (RP <= 8 ? 3 : 2)))) void aggregate3_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
                                                          uint8_t *__restrict__ E, uint16_t *__restrict__ BL,
                                                          uint16_t *__restrict__ SB, const Agg2Args a)
@@ -366,14 +372,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         return;
 
     // ---- steps 1 .. len-1; ring slot i holds a step t with (t-1) % PF == i
-    u32 qwl[PF][RP], qwh[PF][RP], qcl[PF];
+    static_assert(HZ == 0 || PF % RP == 0, "the window shifts become renaming only over a multiple of RP steps");
+    u32 qwl[HZ ? 1 : PF][RP], qwh[HZ ? 1 : PF][RP], qcl[PF];
+    u32 W[RP], WH[RP], qnw[PF]; // HZ: the windows of the next step; slot i: the word that enters after its step
+    // HZ: the word that enters lane 0 when the path moves on to pixel x: censR[x] (low half, dx > 0) or
+    // censR[x - (Dp-1)] (high half, dx < 0); every lane of the row loads it (one address per row)
+    const unsigned voN = (unsigned)((g.y0 * wp + (HZ > 0 ? Dp + g.x0 : g.x0 + 1)) * 4);
+    if constexpr (HZ != 0) {
+        buf_load_win<RP>(rsR, voRl, soR0 + sR, W);
+        buf_load_win<RP>(rsR, voRh, soR0 + sR, WH);
 #pragma unroll
-    for (int i = 0; i < PF; i++)
-        if (1 + i < len) {
-            buf_load_win<RP>(rsR, voRl, soR0 + (1 + i) * sR, qwl[i]);
-            buf_load_win<RP>(rsR, voRh, soR0 + (1 + i) * sR, qwh[i]);
-            qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0 + (1 + i) * sL, 0);
+        for (int i = 0; i < PF; i++) {
+            if (1 + i < len)
+                qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0 + (1 + i) * sL, 0);
+            if (2 + i < len)
+                qnw[i] = __builtin_amdgcn_raw_buffer_load_b32(rsR, voN, soR0 + (2 + i) * sR, 0);
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PF; i++)
+            if (1 + i < len) {
+                buf_load_win<RP>(rsR, voRl, soR0 + (1 + i) * sR, qwl[i]);
+                buf_load_win<RP>(rsR, voRh, soR0 + (1 + i) * sR, qwh[i]);
+                qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0 + (1 + i) * sL, 0);
+            }
+    }
     u32 *bl_last = BLf + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
 
     unsigned soRp = soR0 + (1 + PF) * sR, soLp = soL0 + (1 + PF) * sL; // soffsets of the step PF ahead
@@ -385,11 +408,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         u32 wl[RP], wh[RP];
 #pragma unroll
         for (int j = 0; j < RP; j++) {
-            wl[j] = qwl[i][j];
-            wh[j] = qwh[i][j];
+            wl[j] = HZ ? W[j] : qwl[i][j];
+            wh[j] = HZ ? WH[j] : qwh[i][j];
         }
         const u32 clv = qcl[i];
+        if constexpr (HZ != 0) { // move the windows on to the next pixel (the step works on its copies wl / wh)
+            const u32 nw = qnw[i];
+            if constexpr (HZ > 0) {
+                const u32 inl = dpp<0x111>(nw, W[0]);   // row_shr:1 -- lane q-1's oldest low word; lane 0: the new word
+                const u32 inh = dpp<0x101>(W[0], WH[0]); // row_shl:1 -- lane q+1's oldest high word; lane 15: its own low one
+#pragma unroll
+                for (int j = 0; j + 1 < RP; j++) {
+                    W[j] = W[j + 1];
+                    WH[j] = WH[j + 1];
+                }
+                W[RP - 1] = inl;
+                WH[RP - 1] = inh;
+            } else {
+                const u32 inl = dpp<0x101>(WH[RP - 1], W[RP - 1]);  // row_shl:1 -- lane 15: its own top high word
+                const u32 inh = dpp<0x111>(nw, WH[RP - 1]);         // row_shr:1 -- lane 0: the new word
+#pragma unroll
+                for (int j = RP - 1; j > 0; j--) {
+                    W[j] = W[j - 1];
+                    WH[j] = WH[j - 1];
+                }
+                W[0] = inl;
+                WH[0] = inh;
+            }
+        }
         auto prefetch = [&]() { // census words PF steps ahead, into the ring slot this step has just consumed
+            if constexpr (HZ != 0) {
+                if (!SLOW || t + PF < len)
+                    qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
+                if (!SLOW || t + PF + 1 < len) // (fast blocks end two blocks and a step before the path does)
+                    qnw[i] = __builtin_amdgcn_raw_buffer_load_b32(rsR, voN, soRp + sR, 0);
+            } else
 #ifdef SGMX_EXP_NOLOAD // timing-only build (wrong results): the steady-state loops without their census loads
             if (SLOW && t + PF < len) {
 #else
@@ -516,10 +569,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             for (int i = 0; i < PF; i++)
                 step(maskc, BoolC<false>(), edgec, t + i, i);
             t += PF;
-        } while (t + 2 * PF <= minlen && unmasked(t) != decltype(maskc)::value);
+        } while (t + 2 * PF + (HZ ? 1 : 0) <= minlen && unmasked(t) != decltype(maskc)::value);
     };
     while (t < maxlen) {
-        if (t + 2 * PF <= minlen) { // every row: steps t..t+PF-1 and their prefetch targets exist, none is last
+        if (t + 2 * PF + (HZ ? 1 : 0) <= minlen) { // every row: steps t..t+PF-1 and their prefetch targets exist, none is last
             if (!unmasked(t))
                 run(BoolC<true>(), BoolC<true>());
             else if (any_edge)
