@@ -1,29 +1,48 @@
-"""Experiment: two engines on two streams, so one half's HBM-bound WTA overlaps the other half's VALU-bound sweeps.
-usage: python exp/overlap.py B_per_engine n_engines steps"""
-import sys, time, os
+"""Timing experiment: do sweeps (VALU-bound) and WTA (HBM-bound) of different pair groups overlap when they
+are issued on different streams?  G contexts of B/G pairs each, one stream each, vs one context of B pairs."""
+import argparse, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import stereo_vision_amd as sv
-from bench import synthetic_pair
-B, NE, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-W, H, D = 1241, 376, 128
-pairs = [synthetic_pair(1234 + i, H, W, 100) for i in range(8)]
-Lh = np.stack([pairs[i % 8][0] for i in range(B)]); Rh = np.stack([pairs[i % 8][1] for i in range(B)])
-engs, bufs, streams = [], [], []
-for e in range(NE):
-    engs.append(sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=5, penalty1=3, penalty2=60, num_paths=8, max_batch=B)))
-    bufs.append((torch.from_numpy(Lh).cuda(), torch.from_numpy(Rh).cuda(), torch.zeros((B, H, W), dtype=torch.int16, device="cuda")))
-    streams.append(torch.cuda.Stream())
-def step():
-    for e in range(NE):
-        dL, dR, dO = bufs[e]
-        engs[e].compute_device(dL.data_ptr(), dR.data_ptr(), dO.data_ptr(), B, W, H, streams[e].cuda_stream)
-for _ in range(2): step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(steps): step()
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print("B=%d x %d engines: %.1f frames/s, %.3f ms per %d pairs" % (B, NE, B * NE * steps / dt, dt / steps * 1e3, B * NE))
-same = all(torch.equal(bufs[0][2], bufs[e][2]) for e in range(NE))
-print("outputs identical across engines:", same)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--groups", type=int, default=2)
+ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--stagger", type=int, default=1)
+ap.add_argument("--width", type=int, default=1241)
+ap.add_argument("--height", type=int, default=376)
+ap.add_argument("--disp", type=int, default=128)
+a = ap.parse_args()
+W, H, B, G = a.width, a.height, a.batch, a.groups
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(1)
+L = torch.randint(0, 256, (B, H, W), dtype=torch.uint8, generator=g).to(dev)
+R = torch.randint(0, 256, (B, H, W), dtype=torch.uint8, generator=g).to(dev)
+out = torch.zeros((B, H, W), dtype=torch.uint16, device=dev)
+n = B // G
+engs = [sv.StereoSGM(sv.StereoSGMParams(disp_range=a.disp, window_sz=5, penalty1=3, penalty2=60, max_batch=n)) for _ in range(G)]
+streams = [torch.cuda.Stream() for _ in range(G)]
+
+def one_step():
+    for k in range(G):
+        engs[k].compute_device(L[k * n].data_ptr(), R[k * n].data_ptr(), out[k * n].data_ptr(), n, W, H,
+                               stream=streams[k].cuda_stream)
+
+def run(steps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+run(5)
+if a.stagger and G > 1:
+    # start the streams a part of a phase apart: stream k first runs k * stagger pairs alone
+    for k in range(1, G):
+        m = min(n, k * a.stagger)
+        engs[k].compute_device(L[k * n].data_ptr(), R[k * n].data_ptr(), out[k * n].data_ptr(), m, W, H,
+                               stream=streams[k].cuda_stream)
+ms = run(a.steps)
+print("groups %d x %d pairs: %.3f ms per %d pairs -> %.0f frames/s" % (G, n, ms, B, B / ms * 1e3))

@@ -2,7 +2,7 @@
 compiler's assembly (make -C stereo_vision_amd/csrc asm): counts per opcode over the PF-step loop body / PF."""
 import collections, re, sys
 S = sys.argv[1] if len(sys.argv) > 1 else "/tmp/sgmx-hip-amdgcn-amd-amdhsa-gfx950.s"
-name = sys.argv[2] if len(sys.argv) > 2 else "_ZN4sgmx17aggregate3_kernelILi4ELb0ELb0ELi4EEEvPKjS2_PhPtS4_NS_8Agg2ArgsE"
+name = sys.argv[2] if len(sys.argv) > 2 else "_ZN4sgmx17aggregate3_kernelILi4ELb0ELb0ELi4ELi0EEEvPKjS2_PhPtS4_NS_8Agg2ArgsE"
 PF = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 lines = open(S).read().split(name + ":")[1].split("s_endpgm")[0].splitlines()
 # the first inner loop (Depth=2) after the dispatcher is the unmasked / no-edge one: the loop whose body has no cndmask

@@ -414,7 +414,7 @@ template <int RP> hipError_t launch_agg3(bool first, bool pad, dim3 grid, hipStr
 #define SGMX_HZ 1
 #endif
     if constexpr (SGMX_HZ && RP <= 8) {
-        constexpr int PFH = RP == 8 ? 8 : 4;
+        constexpr int PFH = 8;
         if (a.dy == 0 && !first) {
             if (a.dx > 0)
                 return pad ? go(aggregate3_kernel<RP, false, true, PFH, 1>) : go(aggregate3_kernel<RP, false, false, PFH, 1>);
