@@ -166,6 +166,22 @@ def test_seeded_random_configurations(oracle, case):
         e.close()
 
 
+@pytest.mark.parametrize("D", [16, 40, 100, 128, 130, 256])
+def test_horizontal_sweep_block_boundaries(oracle, D):
+    """The horizontal sweeps keep their census windows in registers and shift them by one word per step, in blocks
+    of 8 steps that need 2 x 8 + 1 pixels of path ahead of them (aggregate3_kernel, HZ): cropped widths around
+    every block boundary, disparity ranges of every lane layout with and without pad disparities, three pairs per
+    launch so that the 16-lane rows of a wave walk different image rows.  stereo_sgm.cc:191-268."""
+    for w in (15, 16, 17, 18, 19, 24, 25, 26, 27, 33, 34, 35, 41, 42):
+        H, W = 11, w + 4
+        pairs = [synth_pair(w * 31 + D + k, H, W, max(1, min(D, W // 2))) for k in range(3)]
+        e = make(disp_range=D, window_sz=5, penalty1=3, penalty2=60, max_batch=3)
+        got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+        for k, (left, right) in enumerate(pairs):
+            assert np.array_equal(got[k], oracle.sgm_census(left, right, D, 5, 3, 60, 8)), "w=%d pair %d" % (w, k)
+        e.close()
+
+
 @pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
 @pytest.mark.parametrize("shape", [(5, 5), (6, 40), (40, 6), (5, 300), (6, 6), (7, 5), (5, 7)])
 def test_degenerate_shapes(oracle, shape, flags):
