@@ -624,17 +624,29 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
 int run_descriptor_cost(sgmx_ctx *c, bool replicate, const float *d_fl, const float *d_fr, int W, int H, int K, hipStream_t st)
 {
     const int D = c->prm.disp_range;
-    const size_t lds = desc_lds_bytes(D, c->Dp);
-    const void *fn = replicate ? (const void *)descriptor_cost_kernel<true> : (const void *)descriptor_cost_kernel<false>;
-    if (lds > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = desc_lds_bytes(c->Dp);
     const int TX = desc_tile_pixels(c->Dp);
     const dim3 grid((W + TX - 1) / TX, H);
+    auto go = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(DESC_THREADS), lds, st, d_fl, d_fr, W, K, D, (float *)c->d_C);
+        return hipSuccess;
+    };
     ProfScope ps(c, SGMX_K_HAMMING, st); // data-cost class
-    if (replicate)
-        hipLaunchKernelGGL(descriptor_cost_kernel<true>, grid, dim3(256), lds, st, d_fl, d_fr, W, K, D, c->Dp, (float *)c->d_C);
+    hipError_t le;
+    if (c->Dp == 128)
+        le = replicate ? go(descriptor_cost_kernel<true, 4, 4>) : go(descriptor_cost_kernel<false, 4, 4>);
+    else if (c->Dp == 256)
+        le = replicate ? go(descriptor_cost_kernel<true, 4, 8>) : go(descriptor_cost_kernel<false, 4, 8>);
+    else if (c->Dp == 512)
+        le = replicate ? go(descriptor_cost_kernel<true, 2, 16>) : go(descriptor_cost_kernel<false, 2, 16>);
     else
-        hipLaunchKernelGGL(descriptor_cost_kernel<false>, grid, dim3(256), lds, st, d_fl, d_fr, W, K, D, c->Dp, (float *)c->d_C);
+        return fail(c, SGMX_ERR_STATE, "descriptor cost: unexpected volume pitch");
+    HIPCHK(c, le);
     HIPCHK(c, hipGetLastError());
     return SGMX_OK;
 }

@@ -822,77 +822,69 @@ __global__ __launch_bounds__(256) void data_cost_wta_kernel(const uint8_t *__res
 // REPLICATE: recon::SGMStereo's variant (new_sgm/sgm_stereo.cc:158-181), which repeats the cost of
 // the last valid disparity d = x where x < d instead of FLT_MAX (:174).
 //
-// A banded contraction: output pixel x needs the right descriptors x-D+1 .. x.  One workgroup owns TX = 4096 / Dp
-// neighbouring pixels of one image row and all Dp disparities; the TX left descriptors and the TX + D - 1 right
-// descriptors go through LDS in chunks of KC = 32 components (row pitch 36 floats: lanes along d read
-// neighbouring rows as 16-byte pieces without bank conflicts), every thread keeps 16 running sums (its
-// disparity, 16 pixels / disparity pairs of the tile) across the chunks, so each descriptor is read from HBM
-// once per tile instead of once per voxel.  HBM bytes: 2 H W K 4 in (the right rows (TX + D - 1) / TX times,
-// from L2), H W Dp 4 out.
-constexpr int DESC_KC = 32, DESC_KCP = 36, DESC_NV = 16;
-inline int desc_tile_pixels(int Dp) { return 4096 / Dp; }
-inline size_t desc_lds_bytes(int D, int Dp) { return (size_t)(2 * desc_tile_pixels(Dp) + D - 1) * DESC_KCP * sizeof(float); }
+// A banded contraction: output pixel x needs the right descriptors x-D+1 .. x.  One workgroup of 1024 threads owns
+// TX = 32 NI neighbouring pixels of one image row and all Dp = 32 NJ disparities; the TX left descriptors and the
+// TX + Dp - 1 right descriptors go through LDS in chunks of KC = 32 components (row pitch 36 floats: lanes along d
+// read neighbouring rows as 16-byte pieces without bank conflicts).  Thread (tx, td), td = lane-fast, keeps the
+// NI x NJ running sums of pixels tx + 32 i and disparities td + 32 j: both strides are 32, so the right descriptor
+// of voxel (i, j), pixel - disparity = (tx - td) + 32 (i - j), is one of only NI + NJ - 1 LDS rows, each read
+// once per four components and used for every (i, j) on its diagonal -- 11 LDS reads of 16 bytes per 192 float
+// operations at Dp = 128 (the round-2 first version read two per voxel and was bound by LDS bandwidth).  Each
+// descriptor is read from HBM once per tile.  HBM bytes: 2 H W K 4 in (the right rows (TX + Dp - 1) / TX times,
+// mostly from L2), H W Dp 4 out.
+constexpr int DESC_KC = 32, DESC_KCP = 36, DESC_THREADS = 1024;
+inline int desc_ni(int Dp) { return Dp <= 256 ? 4 : 2; }
+inline int desc_tile_pixels(int Dp) { return 32 * desc_ni(Dp); }
+inline size_t desc_lds_bytes(int Dp) { return (size_t)(2 * desc_tile_pixels(Dp) + Dp - 1) * DESC_KCP * sizeof(float); }
 
-#ifndef SGMX_DESC_WPE
-#define SGMX_DESC_WPE 3
-#endif
-template <bool REPLICATE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGMX_DESC_WPE))) void descriptor_cost_kernel(const float *__restrict__ fl, const float *__restrict__ fr,
-                                                              int w, int K, int D, int Dp, float *__restrict__ C)
+template <bool REPLICATE, int NI, int NJ>
+__global__ __launch_bounds__(DESC_THREADS) __attribute__((amdgpu_waves_per_eu(NI * NJ <= 16 ? 8 : 4))) void descriptor_cost_kernel(const float *__restrict__ fl, const float *__restrict__ fr,
+                                                                       int w, int K, int D, float *__restrict__ C)
 {
     extern __shared__ __attribute__((aligned(16))) float desc_lds[];
-    const int lg = 31 - __builtin_clz((unsigned)Dp); // Dp = 128, 256 or 512
-    const int TX = 4096 >> lg, NB = TX + D - 1;
+    constexpr int TX = 32 * NI, Dp = 32 * NJ, NB = TX + Dp - 1;
     float *A = desc_lds;                   // [TX][KCP]   left descriptors x0 .. x0 + TX - 1
-    float *B = desc_lds + TX * DESC_KCP;   // [NB][KCP]   right descriptors x0 - D + 1 .. x0 + TX - 1 (zeros left of the image)
+    float *B = desc_lds + TX * DESC_KCP;   // [NB][KCP]   right descriptors x0 - Dp + 1 .. x0 + TX - 1 (zeros left of the image)
     const int x0 = blockIdx.x * TX, y = blockIdx.y;
     const size_t row = (size_t)y * w;
-    const int tid = threadIdx.x;
-    // voxel v = tid + 256 i of the tile's TX x Dp: x = v / Dp, d = v % Dp
-    float s[DESC_NV];
-    int boff[DESC_NV];
-    const int a0 = (tid >> lg) * DESC_KCP, astep = (256 >> lg) * DESC_KCP; // pixel of voxel i: (tid >> lg) + (256 >> lg) i
+    const int tid = threadIdx.x, td = tid & 31, tx = tid >> 5;
+    float s[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < DESC_NV; i++) {
-        const int v = tid + 256 * i, xl = v >> lg, d = v & (Dp - 1);
-        const int x = x0 + xl;
-        int dd = d < D ? d : 0;
-        dd = dd > x ? (x < 0 ? 0 : x) : dd; // d > x: the row of d = x (used by REPLICATE, overwritten otherwise)
-        s[i] = 0.f;
-        boff[i] = (xl - dd + D - 1) * DESC_KCP;
-    }
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+            s[i][j] = 0.f;
+    const float *Ap = A + tx * DESC_KCP;
+    const float *Bp = B + (tx - td + Dp - 1) * DESC_KCP; // the row of i - j = 0
     for (int k0 = 0; k0 < K; k0 += DESC_KC) {
         const int kc = K - k0 < DESC_KC ? K - k0 : DESC_KC;
         __syncthreads(); // the previous chunk has been consumed
-        // fill: (TX + NB) rows of 32 components; components past K and rows left of the image hold 0 (a zero
-        // difference leaves a sum unchanged).  16-byte pieces, all of a thread's loads in flight before its first
-        // LDS store (a piece per thread and pass in a dependent loop made the kernel latency-bound: 1.9 ms).
+        // fill: (TX + NB) rows of 32 components; components past K and rows left / right of the image hold 0 (a
+        // zero difference leaves a sum unchanged).  16-byte pieces, all of a thread's loads in flight before its
+        // first LDS store.
         if ((K & 3) == 0) {
-            constexpr int PIECES = DESC_KC / 4, MAXP = 8;
-            const int npiece = (TX + NB) * PIECES;
-            for (int e0 = 0; e0 < npiece; e0 += 256 * MAXP) {
-                float4 v[MAXP];
+            constexpr int PIECES = DESC_KC / 4, NPIECE = (TX + NB) * PIECES, MAXP = (NPIECE + DESC_THREADS - 1) / DESC_THREADS;
+            float4 v[MAXP];
 #pragma unroll
-                for (int m = 0; m < MAXP; m++) {
-                    const int e = e0 + tid + 256 * m, r = e / PIECES, k = (e % PIECES) * 4;
-                    v[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < npiece && k < kc) {
-                        const int x = r < TX ? x0 + r : x0 - (D - 1) + (r - TX);
-                        if (x >= 0 && x < w)
-                            v[m] = *reinterpret_cast<const float4 *>((r < TX ? fl : fr) + (row + x) * K + k0 + k);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < MAXP; m++) {
-                    const int e = e0 + tid + 256 * m, r = e / PIECES, k = (e % PIECES) * 4;
-                    if (e < npiece)
-                        *reinterpret_cast<float4 *>((r < TX ? A + r * DESC_KCP : B + (r - TX) * DESC_KCP) + k) = v[m];
+            for (int m = 0; m < MAXP; m++) {
+                const int e = tid + DESC_THREADS * m, r = e / PIECES, k = (e % PIECES) * 4;
+                v[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NPIECE && k < kc) {
+                    const int x = r < TX ? x0 + r : x0 - (Dp - 1) + (r - TX);
+                    if (x >= 0 && x < w)
+                        v[m] = *reinterpret_cast<const float4 *>((r < TX ? fl : fr) + (row + x) * K + k0 + k);
                 }
             }
+#pragma unroll
+            for (int m = 0; m < MAXP; m++) {
+                const int e = tid + DESC_THREADS * m, r = e / PIECES, k = (e % PIECES) * 4;
+                if (e < NPIECE)
+                    *reinterpret_cast<float4 *>((r < TX ? A + r * DESC_KCP : B + (r - TX) * DESC_KCP) + k) = v[m];
+            }
         } else {
-            for (int e = tid; e < (TX + NB) * DESC_KC; e += 256) {
+            for (int e = tid; e < (TX + NB) * DESC_KC; e += DESC_THREADS) {
                 const int r = e / DESC_KC, k = e % DESC_KC;
-                const int x = r < TX ? x0 + r : x0 - (D - 1) + (r - TX);
+                const int x = r < TX ? x0 + r : x0 - (Dp - 1) + (r - TX);
                 float v = 0.f;
                 if (x >= 0 && x < w && k < kc)
                     v = (r < TX ? fl : fr)[(row + x) * K + k0 + k];
@@ -901,37 +893,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGMX_DESC_W
         }
         __syncthreads();
         for (int k = 0; k < kc; k += 4) { // (components past kc are zeros)
+            float4 a[NI];
 #pragma unroll
-            for (int i = 0; i < DESC_NV; i++) {
-                if (i % 4 == 0)
-                    __builtin_amdgcn_sched_barrier(0); // four voxels' LDS reads in flight at a time, not sixteen (registers)
-                const float4 a = *reinterpret_cast<const float4 *>(A + a0 + i * astep + k);
-                const float4 b = *reinterpret_cast<const float4 *>(B + boff[i] + k);
-                float df = a.x - b.x;
-                s[i] += df * df;
-                df = a.y - b.y;
-                s[i] += df * df;
-                df = a.z - b.z;
-                s[i] += df * df;
-                df = a.w - b.w;
-                s[i] += df * df;
+            for (int i = 0; i < NI; i++)
+                a[i] = *reinterpret_cast<const float4 *>(Ap + 32 * i * DESC_KCP + k);
+#pragma unroll
+            for (int dl = -(NJ - 1); dl <= NI - 1; dl++) { // the diagonal i - j = dl shares one right descriptor
+                // two diagonals' reads in flight at a time, not all of them: 64 VGPRs let two workgroups share a CU,
+                // one filling its chunk while the other computes
+                if ((dl + NJ - 1) % 2 == 0)
+                    __builtin_amdgcn_sched_barrier(0);
+                const float4 b = *reinterpret_cast<const float4 *>(Bp + 32 * dl * DESC_KCP + k);
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const int j = i - dl;
+                    if (j < 0 || j >= NJ)
+                        continue;
+                    // left to right over the components, one rounding per operation (no contraction)
+                    float df = a[i].x - b.x;
+                    s[i][j] += df * df;
+                    df = a[i].y - b.y;
+                    s[i][j] += df * df;
+                    df = a[i].z - b.z;
+                    s[i][j] += df * df;
+                    df = a[i].w - b.w;
+                    s[i][j] += df * df;
+                }
             }
         }
     }
+    // REPLICATE: the voxels with d > x take the cost of d = x, which another thread of this workgroup holds
+    float *diag = desc_lds; // [TX]
+    if (REPLICATE && x0 < D) {
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < DESC_NV; i++) {
-        const int v = tid + 256 * i, xl = v >> lg, d = v & (Dp - 1);
-        const int x = x0 + xl;
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                if (x0 + tx + 32 * i == td + 32 * j)
+                    diag[tx + 32 * i] = __builtin_sqrtf(s[i][j]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int xl = tx + 32 * i, x = x0 + xl;
         if (x >= w)
             continue;
-        float o;
-        if (d >= D)
-            o = 0.f;
-        else if (d > x && !REPLICATE)
-            o = 3.402823466e+38f;
-        else
-            o = __builtin_sqrtf(s[i]);
-        C[(row + x) * Dp + d] = o;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int d = td + 32 * j;
+            float o;
+            if (d >= D)
+                o = 0.f;
+            else if (d > x)
+                o = REPLICATE ? diag[xl] : 3.402823466e+38f;
+            else
+                o = __builtin_sqrtf(s[i][j]);
+            C[(row + x) * Dp + d] = o;
+        }
     }
 }
 

@@ -25,7 +25,11 @@ def _descs(seed, H, W, K, shift=3):
     return fl, fr
 
 
-@pytest.mark.parametrize("case", [(18, 80, 8, 32), (12, 150, 64, 100), (9, 40, 1, 16)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(18, 80, 8, 32), (12, 150, 64, 100), (9, 40, 1, 16),
+                                  # every register tile of descriptor_cost_kernel (volume pitch 128 / 256 / 512), several
+                                  # pixel tiles per row, K past one LDS chunk with and without a multiple of 4
+                                  (7, 300, 38, 200), (6, 200, 12, 300), (5, 270, 68, 128)],
+                         ids=lambda c: "x".join(map(str, c)))
 def test_descriptor_path(oracle, case):
     """recon::SGM::Compute from descriptors (sgm.cc:76-84 on the GPU).  Parity unpinned by the
     reference (Eigen's .norm() order); checked against the oracle's left-to-right float sum."""
