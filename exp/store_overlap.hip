@@ -84,7 +84,7 @@ template <int K, int PF> float runl(unsigned char *buf, const u32 *tab, int T, l
 
 // the vertical D = 256 sweep's memory side: per step four 16-byte loads per lane (windows of a census row that stays in
 // cache: 4 KB per wave and step through the L1 path), consumed PF steps later, and the 1 KB store
-template <int K, int PF>
+template <int K, int PF, bool ROWS = false>
 __global__ __launch_bounds__(256) void kv(unsigned char *out, const u32 *tab, int T, long wave_stride, long step_stride)
 {
     const int lane = threadIdx.x & 63;
@@ -92,21 +92,26 @@ __global__ __launch_bounds__(256) void kv(unsigned char *out, const u32 *tab, in
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + wave * wave_stride, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32 *>(tab), 0, -1, 0x00020000);
     u32 a = lane, b = lane * 3 + 1, c = 7, d = 9;
-    unsigned so = 0, sl = (unsigned)(wave & 63) * 1024;
-    const unsigned vo = (lane & 15) * 32 + (lane >> 4) * 4;
+    // ROWS: the waves of one XCD (blockIdx % 8: a "pair") read their windows from one 16 KB "census row" per step, a
+    // new row every step (32 MB per pair and launch: the rows miss the XCD's 4 MB L2 on first touch, like a 4K image)
+    const unsigned pairw = (unsigned)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    unsigned so = 0, sl = ROWS ? (unsigned)(blockIdx.x & 7) * (32u << 20) : (unsigned)(wave & 63) * 1024;
+    const unsigned vo = (lane & 15) * 32 + (lane >> 4) * 4 + (ROWS ? pairw * 16 : 0);
+    constexpr unsigned LSTEP = ROWS ? 16384 : 4096;
     u32x4 q[PF][4];
 #pragma unroll
     for (int i = 0; i < PF; i++)
 #pragma unroll
         for (int m = 0; m < 4; m++)
-            q[i][m] = __builtin_amdgcn_raw_buffer_load_b128(rt, vo + 16 * (m & 1) + 1024 * (m >> 1), sl + 4096 * i, 0);
+            q[i][m] = __builtin_amdgcn_raw_buffer_load_b128(rt, vo + 16 * (m & 1) + 1024 * (m >> 1), sl + LSTEP * i, 0);
+    sl += LSTEP * (PF - 1);
     for (int t = 0; t < T; t += PF) {
 #pragma unroll
         for (int i = 0; i < PF; i++) {
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 a ^= q[i][m].x ^ q[i][m].y ^ q[i][m].z ^ q[i][m].w;
-            sl = (sl + 4096) & 0xFFFFF; // a 1 MB table: stays in L2
+            sl = ROWS ? sl + LSTEP : ((sl + 4096) & 0xFFFFF); // not ROWS: a 1 MB table that stays in L2
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 q[i][m] = __builtin_amdgcn_raw_buffer_load_b128(rt, vo + 16 * (m & 1) + 1024 * (m >> 1), sl, 0);
@@ -124,14 +129,14 @@ __global__ __launch_bounds__(256) void kv(unsigned char *out, const u32 *tab, in
         }
     }
 }
-template <int K, int PF> float runv(unsigned char *buf, const u32 *tab, int T, long ws, long ss)
+template <int K, int PF, bool ROWS = false> float runv(unsigned char *buf, const u32 *tab, int T, long ws, long ss)
 {
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((kv<K, PF>), dim3(1024), dim3(256), 0, 0, buf, tab, T, ws, ss);
+    hipLaunchKernelGGL((kv<K, PF, ROWS>), dim3(1024), dim3(256), 0, 0, buf, tab, T, ws, ss);
     CHK(hipEventRecord(e0));
     for (int r = 0; r < 3; r++)
-        hipLaunchKernelGGL((kv<K, PF>), dim3(1024), dim3(256), 0, 0, buf, tab, T, ws, ss);
+        hipLaunchKernelGGL((kv<K, PF, ROWS>), dim3(1024), dim3(256), 0, 0, buf, tab, T, ws, ss);
     CHK(hipEventRecord(e1));
     CHK(hipEventSynchronize(e1));
     float ms;
@@ -224,11 +229,15 @@ int main()
     ROWL(0) ROWL(32) ROWL(64) ROWL(88) ROWL(128)
     {
         u32 *big;
-        CHK(hipMalloc(&big, (2 << 20) + 65536));
-        CHK(hipMemset(big, 1, (2 << 20) + 65536));
+        const size_t bigb = ((size_t)8 * 32 << 20) + ((size_t)(2048 + 8) * 16384);
+        CHK(hipMalloc(&big, bigb));
+        CHK(hipMemset(big, 1, bigb));
         const float a = runv<88, 2>(buf, big, T, ws_row, ss_row), b = runv<88, 4>(buf, big, T, ws_row, ss_row);
         printf("K =  88 (16 of them the xors of the loaded words) + 4 x 16-byte loads per lane and step (4 KB per wave, L2 resident), rows nt: "
                "PF 2 %7.3f ms %5.2f TB/s | PF 4 %7.3f ms %5.2f TB/s\n", a, bytes / a / 1e9, b, bytes / b / 1e9);
+        const float c = runv<88, 2, true>(buf, big, T, ws_row, ss_row), d = runv<88, 4, true>(buf, big, T, ws_row, ss_row);
+        printf("    the same, the windows from a new 16 KB row per step and XCD (first touch misses L2): "
+               "PF 2 %7.3f ms %5.2f TB/s | PF 4 %7.3f ms %5.2f TB/s\n", c, bytes / c / 1e9, d, bytes / d / 1e9);
     }
     {
         const int T2 = 4096;

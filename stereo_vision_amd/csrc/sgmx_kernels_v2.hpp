@@ -452,8 +452,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
                 buf_load_win<RP>(rsR, voRh, soRp, qwh[i]);
                 qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
             }
+#ifndef SGMX_EXP_FIXLOAD // (defined: timing-only, every step loads the census words of the path's first pixels again)
             soRp += sR;
             soLp += sL;
+#endif
         };
         if (SLOW)
             prefetch();
@@ -505,8 +507,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
 #pragma unroll
             for (int j = 0; j < RP; j++) {
                 u32 lo, hi;
+#ifdef SGMX_EXP_NOLOAD // (timing-only: the census words are loop invariant there; volatile keeps the popcounts in the loop)
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(lo) : "v"(wl[RP - 1 - j] ^ ncl), "v"(e[j]));
+                asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(hi) : "v"(wh[j] ^ ncl));
+#else
                 asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(lo) : "v"(wl[RP - 1 - j] ^ ncl), "v"(e[j]));
                 asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(hi) : "v"(wh[j] ^ ncl));
+#endif
                 asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(prior[j]) : "v"(hi), "v"(lo));
                 if (HAS_PAD)
                     prior[j] &= padmask[j];
