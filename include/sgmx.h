@@ -261,7 +261,11 @@ SGMX_API int sgmx_match_hamming_thres_nt(sgmx_ctx *ctx, const uint8_t *bs1, cons
 SGMX_API void sgmx_free(void *ptr);
 
 /* After a compute call, copy stages of pair `index` (0-based within the last
- * launch group) to the host: the data cost C [h][w][D] (uint8 for the census
+ * launch group: a call runs its pairs in launches of at most max_batch pairs,
+ * on the volume-free census path also of at most 32 pairs and at most 208 MB
+ * of census images -- 3 pairs at 3840 x 2160 with disp_range 256 -- so that
+ * the images stay cache resident between the direction sweeps; a call with
+ * one pair always has index 0) to the host: the data cost C [h][w][D] (uint8 for the census
  * path -- costs at stereo_sgm.cc:31-51; float for the float path), the summed
  * path costs S [h][w][D] (aggr_costs, stereo_sgm.cc:133 / sgm.cc:116; uint16 here,
  * uint32 in the reference, same values), the disparity image before the median

@@ -474,6 +474,12 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
     } restore{c, was_profiling};
     HIPCHK(c, hipMemsetAsync(v.BL, 0, v.bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
     HIPCHK(c, hipMemsetAsync(v.SB, 0, v.bytes_BL * n, st));
+    { // the launch's census images into the memory-side cache before the first sweep (cache_warm_kernel)
+        const size_t ncl = (size_t)n * v.w * v.h * 4 / 16, ncr = (size_t)n * v.wp * v.h * 4 / 16;
+        hipLaunchKernelGGL(cache_warm_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(v.cl), ncl, (u32 *)v.BL);
+        hipLaunchKernelGGL(cache_warm_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(v.cr), ncr, (u32 *)v.BL);
+        HIPCHK(c, hipGetLastError());
+    }
     const bool pad = c->prm.disp_range != c->DpF;
     for (int k = 0; k < np; k++) {
         Agg2Args a;
@@ -593,9 +599,39 @@ int run_census(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, int W, 
 // One launch group (n <= max_batch) of the census path on the context's scratch, everything device resident.
 // Both formulations give the same bits; contexts with P2 <= 255 run the volume-free one (sgmx_kernels_v2.hpp),
 // the faster one at every group size measured.
+// Pairs per kernel launch on the volume-free path.  Every direction sweep reads the census images of all pairs of
+// the launch again, in between its G stores.  Measured: while those images stay in the 256 MB
+// Infinity Cache next to the write stream (~208 MB of them: 3 pairs at 3840 x 2160, D = 256) the reads cost
+// nothing; once they come from HBM the sweeps take 20-40 % longer (8 such pairs per launch: 5.5 ms per pair and
+// direction against 4.6 for 3).  And beyond 4 pairs per XCD (32) the images of the pairs an XCD works on
+// overflow its L2 several times over (KITTI size: 32 pairs 5 140 frames/s, 48: 4 730, 64: 3 800).
+int fast_launch_pairs(const sgmx_ctx *c, int w, int h, int wp)
+{
+    const size_t per = ((size_t)w * h + (size_t)wp * h) * 4;
+    size_t g = ((size_t)208 << 20) / per;
+    g = g < 1 ? 1 : (g > 32 ? 32 : g);
+    return (int)g < c->prm.max_batch ? (int)g : c->prm.max_batch;
+}
+
 int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint16_t *d_disp, hipStream_t st)
 {
     const int W = c->W, H = c->H, w = c->w, h = c->h;
+    if (c->fast) {
+        // launches of at most fast_launch_pairs pairs, one after the other on the same scratch
+        const int cap = fast_launch_pairs(c, w, h, c->wp);
+        const size_t nfull = (size_t)W * H;
+        int rc = SGMX_OK;
+        for (int i = 0; i < n && !rc; i += cap) {
+            const int k = n - i < cap ? n - i : cap;
+            rc = run_census(c, k, dL + i * nfull, dR + i * nfull, W, H, c->d_cl, c->d_cr, c->wp, c->DpF, st, true);
+            if (!rc)
+                rc = run_fast(c, ctx_view(c), k, d_disp + i * nfull, st, true);
+            c->last_n = k;
+        }
+        if (!rc)
+            rc = scratch_release(c, st);
+        return rc;
+    }
     int rc = run_census(c, n, dL, dR, W, H, c->d_cl, c->d_cr, c->fast ? c->wp : w, c->fast ? c->DpF : 0, st, true);
     if (rc)
         return rc;
@@ -919,7 +955,8 @@ int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *c, int n, const uint8_t *d_left
         return fail(c, SGMX_ERR_INVALID_ARG,
                     "one pair needs " + std::to_string(need(1)) + " bytes of scratch; the no-allocation entry point has " +
                         std::to_string(SGMX_NOALLOC_SCRATCH_BYTES) + " (use sgmx_compute_census_u8_dev)");
-    int g = n < c->prm.max_batch ? n : c->prm.max_batch;
+    int g = fast_launch_pairs(c, w, h, wp);
+    g = n < g ? n : g;
     while (need((size_t)g) > SGMX_NOALLOC_SCRATCH_BYTES)
         g--;
     HIPCHK(c, hipSetDevice(c->prm.device));

@@ -211,3 +211,34 @@ def test_4k_stress_two_formulations_agree():
     mat.close()
     assert np.array_equal(a, c)
     assert np.count_nonzero(a) > 0.5 * a.size  # most pixels pass the LR check on this textured pair
+
+
+def test_large_pairs_run_in_cache_sized_launches():
+    """Pairs whose census images would not stay in the Infinity Cache together are run in several kernel launches
+    inside one call (sgmx.h, stage getters): 3000 x 2000 at D = 64 is 48 MB of census images per pair,
+    so a call with 5 pairs runs 4 + 1.  Every pair must come out as when it is computed alone (the pairs of the
+    reference's batch scripts are independent, scripts/run_sgm_batch_census.py:27-34), and the stage getters must
+    see the last launch, which has one pair."""
+    rng = np.random.default_rng(99)
+    H, W, n = 2000, 3000, 5
+    base = rng.integers(0, 256, size=(n, H, W + 40), dtype=np.uint8)
+    lefts = np.ascontiguousarray(base[:, :, 40:])
+    rights = np.ascontiguousarray(base[:, :, :W])
+    e = sv.StereoSGM(sv.StereoSGMParams(disp_range=64, window_sz=5, penalty1=3, penalty2=60, max_batch=n))
+    got = e.compute_batch(lefts, rights)
+
+    def raw_of(eng, index):  # the disparity image before the median only (C and S would be a gigabyte here)
+        raw = np.empty((H, W), np.uint16)
+        eng.check(eng.lib.sgmx_get_stages_census(eng.h, index, None, None, raw.ctypes.data))
+        return raw
+
+    with pytest.raises(sv.SgmxError):
+        raw_of(e, 1)
+    raw_last = raw_of(e, 0)
+    one = sv.StereoSGM(sv.StereoSGMParams(disp_range=64, window_sz=5, penalty1=3, penalty2=60))
+    for k in (0, 3, 4):
+        assert np.array_equal(got[k], one.compute(lefts[k], rights[k])), "pair %d" % k
+    assert np.array_equal(raw_last, raw_of(one, 0))
+    assert np.count_nonzero(got[4]) > 0.3 * got[4].size
+    e.close()
+    one.close()
