@@ -474,7 +474,9 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
     } restore{c, was_profiling};
     HIPCHK(c, hipMemsetAsync(v.BL, 0, v.bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
     HIPCHK(c, hipMemsetAsync(v.SB, 0, v.bytes_BL * n, st));
-    { // the launch's census images into the memory-side cache before the first sweep (cache_warm_kernel)
+    // the launch's census images into the memory-side cache before the first sweep (cache_warm_kernel); a few
+    // megabytes are still in the L2s the census kernel wrote them through
+    if (((size_t)n * v.w * v.h + (size_t)n * v.wp * v.h) * 4 > ((size_t)16 << 20)) {
         const size_t ncl = (size_t)n * v.w * v.h * 4 / 16, ncr = (size_t)n * v.wp * v.h * 4 / 16;
         hipLaunchKernelGGL(cache_warm_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(v.cl), ncl, (u32 *)v.BL);
         hipLaunchKernelGGL(cache_warm_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(v.cr), ncr, (u32 *)v.BL);
