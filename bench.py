@@ -270,9 +270,12 @@ def main():
         if agg_n:
             h_, w_ = H - 2 * m, W - 2 * m
             Dp = 32 * (1 if D <= 32 else 2 if D <= 64 else 4 if D <= 128 else 8 if D <= 256 else 12 if D <= 384 else 16)
-            model_bytes = B * alg_agg / args.paths
+            # pairs per kernel launch: B, unless the engine runs the call as several launches (more than 32 pairs or
+            # more than 208 MB of census images per launch: DESIGN.md 4)
+            ppl = B * args.paths * args.steps / agg_n
+            model_bytes = ppl * alg_agg / args.paths
             if fast:
-                launch_bytes = B * (h_ * w_ * Dp + h_ * w_ * 4 + h_ * (w_ + Dp) * 4 + 4 * (2 * w_ + 2 * h_) * Dp * 2)
+                launch_bytes = ppl * (h_ * w_ * Dp + h_ * w_ * 4 + h_ * (w_ + Dp) * 4 + 4 * (2 * w_ + 2 * h_) * Dp * 2)
             else:
                 launch_bytes = model_bytes
             avg_s = agg_ms / agg_n * 1e-3
@@ -297,7 +300,7 @@ def main():
             roof = {"bound": "hbm", "kernel": "aggregate3_kernel" if fast else "aggregate_u16_kernel",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": tname, "avg_launch_ms": round(agg_ms / agg_n, 4),
-                    "alg_bytes_per_launch": launch_bytes,
+                    "alg_bytes_per_launch": int(launch_bytes), "pairs_per_launch": round(ppl, 3),
                     "hbm_GBs_from_traffic": round(traffic / avg_s / 1e9, 1) if traffic else None,
                     "valu_issue": valu,
                     "model_bytes_per_launch": model_bytes,
