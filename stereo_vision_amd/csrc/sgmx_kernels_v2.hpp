@@ -416,8 +416,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
 
     unsigned soRp = soR0 + (1 + PF) * sR, soLp = soL0 + (1 + PF) * sL; // soffsets of the step PF ahead
     unsigned soE = soE0, soB = soB0;
-    auto step = [&](auto maskc, auto slowc, auto edgec, int t, int i) {
-        constexpr bool SLOW = decltype(slowc)::value, EDGE = decltype(edgec)::value;
+    // guardc: a steady-state (not SLOW) step near the end of the path, whose prefetch target may lie past it
+    auto step = [&](auto maskc, auto slowc, auto edgec, auto guardc, int t, int i) {
+        constexpr bool SLOW = decltype(slowc)::value, EDGE = decltype(edgec)::value, GUARD = decltype(guardc)::value;
         soE += sE;
         soB += sB;
         u32 wl[RP], wh[RP];
@@ -453,15 +454,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         }
         auto prefetch = [&]() { // census words PF steps ahead, into the ring slot this step has just consumed
             if constexpr (HZ != 0) {
-                if (!SLOW || t + PF < len)
+                if ((!SLOW && !GUARD) || t + PF < len)
                     qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
-                if (!SLOW || t + PF + 1 < len) // (fast blocks end two blocks and a step before the path does)
+                if ((!SLOW && !GUARD) || t + PF + 1 < len) // (fast blocks end two blocks and a step before the path does)
                     qnw[i] = __builtin_amdgcn_raw_buffer_load_b32(rsR, voN, soRp + sR, 0);
             } else
 #ifdef SGMX_EXP_NOLOAD // timing-only build (wrong results): the steady-state loops without their census loads
             if (SLOW && t + PF < len) {
 #else
-            if (!SLOW || t + PF < len) { // (fast blocks: in range for every row)
+            if ((!SLOW && !GUARD) || t + PF < len) { // (fast blocks: in range for every row)
 #endif
                 buf_load_win<RP>(rsR, voRl, soRp, qwl[i]);
                 buf_load_win<RP>(rsR, voRh, soRp, qwh[i]);
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         do {
 #pragma unroll
             for (int i = 0; i < PF; i++)
-                step(maskc, BoolC<false>(), edgec, t + i, i);
+                step(maskc, BoolC<false>(), edgec, BoolC<false>(), t + i, i);
             t += PF;
         } while (t + 2 * PF + (HZ ? 1 : 0) <= minlen && unmasked(t) != decltype(maskc)::value);
     };
@@ -601,11 +602,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
                 run(BoolC<false>(), BoolC<true>());
             else
                 run(BoolC<false>(), BoolC<false>());
+        } else if (t + PF < minlen && !any_edge && unmasked(t)) {
+            // the last full blocks of the paths: none of their steps is a row's last one, but what they prefetch
+            // may lie past a path's end -- the steady-state steps with guarded loads
+#pragma unroll
+            for (int i = 0; i < PF; i++)
+                step(BoolC<false>(), BoolC<false>(), BoolC<false>(), BoolC<true>(), t + i, i);
+            t += PF;
         } else {
 #pragma unroll
             for (int i = 0; i < PF; i++)
                 if (t + i < maxlen)
-                    step(BoolC<true>(), BoolC<true>(), BoolC<true>(), t + i, i);
+                    step(BoolC<true>(), BoolC<true>(), BoolC<true>(), BoolC<false>(), t + i, i);
             t += PF;
         }
     }
