@@ -694,9 +694,10 @@ __device__ __forceinline__ void sum_pixel(const SumArgs &a, const PixelRaw<RP> &
                 acc[m] = r.ev[k0][m];
 #pragma unroll
             for (int k = k0 + 1; k < k0 + G; k++)
+                if (k < a.N) // (4 paths with a group of 8: volumes 4..7 do not exist, load_pixel left their registers alone)
 #pragma unroll
-                for (int m = 0; m < NW; m++)
-                    acc[m] += r.ev[k][m];
+                    for (int m = 0; m < NW; m++)
+                        acc[m] += r.ev[k][m];
 #pragma unroll
             for (int j = 0; j < RP; j++)
                 S[j] = pk_sub(S[j], __builtin_amdgcn_perm(0u, acc[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u));

@@ -166,6 +166,23 @@ def test_seeded_random_configurations(oracle, case):
         e.close()
 
 
+@pytest.mark.parametrize("case", [(16, 156, 16, 5, 2, 4, 4), (17, 105, 16, 7, 6, 11, 4), (36, 327, 64, 3, 7, 26, 4),
+                                  (39, 50, 31, 1, 8, 23, 4), (42, 276, 32, 7, 20, 26, 4), (11, 214, 65, 7, 8, 28, 4),
+                                  (20, 90, 128, 5, 3, 31, 4), (20, 90, 128, 5, 3, 31, 8), (20, 90, 200, 5, 3, 15, 4)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_four_paths_with_small_penalties(oracle, case):
+    """P2 <= 31 lets the final kernel add the G bytes of 8 volumes at a time without carry; with 4 paths only 4
+    volumes exist (found by exp/random_stress.py: the sum used to take in the registers of the 4 that were never
+    loaded).  Three pairs per launch, final disparity against the oracle.  stereo_sgm.h:105-117."""
+    H, W, D, wsz, P1, P2, paths = case
+    pairs = [synth_pair(H * 977 + W * 13 + D + j, H, W, max(1, min(D, W // 2))) for j in range(3)]
+    e = make(disp_range=D, window_sz=wsz, penalty1=P1, penalty2=P2, num_paths=paths, max_batch=3)
+    got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+    e.close()
+    for j, (left, right) in enumerate(pairs):
+        assert np.array_equal(got[j], oracle.sgm_census(left, right, D, wsz, P1, P2, paths)), "pair %d" % j
+
+
 @pytest.mark.parametrize("D", [16, 40, 100, 128, 130, 256])
 def test_horizontal_sweep_block_boundaries(oracle, D):
     """The horizontal sweeps keep their census windows in registers and shift them by one word per step, in blocks
