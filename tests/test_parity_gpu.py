@@ -199,6 +199,19 @@ def test_horizontal_sweep_block_boundaries(oracle, D):
         e.close()
 
 
+@pytest.mark.parametrize("case", _random_configs(64, 777), ids=lambda c: "x".join(map(str, c)))
+def test_seeded_random_configurations_three_pairs(oracle, case):
+    """A second seeded draw (the one exp/random_stress.py starts with), three different pairs per launch: the four
+    rows of a wave then walk paths of different pairs."""
+    H, W, D, wsz, P1, P2, paths = case
+    pairs = [synth_pair(H * 977 + W * 13 + D + j, H, W, max(1, min(D, W // 2))) for j in range(3)]
+    e = make(disp_range=D, window_sz=wsz, penalty1=P1, penalty2=P2, num_paths=paths, max_batch=3)
+    got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+    e.close()
+    for j, (left, right) in enumerate(pairs):
+        assert np.array_equal(got[j], oracle.sgm_census(left, right, D, wsz, P1, P2, paths)), "pair %d" % j
+
+
 @pytest.mark.parametrize("flags", [0, 1], ids=["fast", "materialized"])
 @pytest.mark.parametrize("shape", [(5, 5), (6, 40), (40, 6), (5, 300), (6, 6), (7, 5), (5, 7)])
 def test_degenerate_shapes(oracle, shape, flags):
