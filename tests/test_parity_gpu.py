@@ -230,8 +230,13 @@ def test_strided_input_and_reuse(oracle):
     for seed, (H, W) in enumerate([(30, 64), (18, 100), (30, 64)]):
         l, r = synth_pair(seed, H, W + 9, 12)
         lv, rv = l[:, 4:4 + W], r[:, 4:4 + W]
-        assert np.array_equal(e.compute(lv, rv), oracle.sgm_census(np.ascontiguousarray(lv),
-                                                                   np.ascontiguousarray(rv), 32, 3, 3, 60, 8))
+        want = oracle.sgm_census(np.ascontiguousarray(lv), np.ascontiguousarray(rv), 32, 3, 3, 60, 8)
+        assert np.array_equal(e.compute(lv, rv), want)
+        # and a disparity image with a row pitch of its own (cv::Mat ROI as the output)
+        out = np.full((H, W + 7), 0xABCD, np.uint16)
+        e.check(e.lib.sgmx_compute_census_u8(e.h, lv.ctypes.data, rv.ctypes.data, W, H, lv.strides[0], rv.strides[0],
+                                             out.ctypes.data, out.strides[0]))
+        assert np.array_equal(out[:, :W], want) and (out[:, W:] == 0xABCD).all()
 
 
 # ---------------------------------------------------------------- golden fixtures
