@@ -640,23 +640,20 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
             rc = scratch_release(c, st);
         return rc;
     }
-    int rc = run_census(c, n, dL, dR, W, H, c->d_cl, c->d_cr, c->fast ? c->wp : w, c->fast ? c->DpF : 0, st, true);
+    // the materialised formulation: census, data-cost volume, sweeps over C and S, WTA
+    int rc = run_census(c, n, dL, dR, W, H, c->d_cl, c->d_cr, w, 0, st, true);
     if (rc)
         return rc;
-    if (c->fast) {
-        rc = run_fast(c, ctx_view(c), n, d_disp, st, true);
-    } else {
-        {
-            ProfScope ps(c, SGMX_K_HAMMING, st);
-            const size_t groups = (size_t)n * w * h * (c->Dp / 16);
-            hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, c->d_cl,
-                               c->d_cr, w, 0, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
-            HIPCHK(c, hipGetLastError());
-        }
-        rc = run_aggregation(c, n, false, st, c->d_C);
-        if (!rc)
-            rc = run_wta_median(c, n, false, d_disp, st);
+    {
+        ProfScope ps(c, SGMX_K_HAMMING, st);
+        const size_t groups = (size_t)n * w * h * (c->Dp / 16);
+        hipLaunchKernelGGL(hamming_volume_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, c->d_cl,
+                           c->d_cr, w, 0, w, h, c->prm.disp_range, c->Dp, (uint8_t *)c->d_C, groups);
+        HIPCHK(c, hipGetLastError());
     }
+    rc = run_aggregation(c, n, false, st, c->d_C);
+    if (!rc)
+        rc = run_wta_median(c, n, false, d_disp, st);
     c->last_n = n;
     if (!rc)
         rc = scratch_release(c, st);

@@ -6,36 +6,39 @@
 //     stay cache resident (2 x 1.8 MB per pair), instead of being streamed from a 59 MB volume.
 //   * aggregate_path (stereo_sgm.h:119-147) gives L = C + E with
 //         E = min(prior[d], prior[d+-1] + P1, m + P2) - m,   0 <= E <= P2,
-//     so with P2 <= 255 every direction stores only E as ONE byte per voxel into its own volume
-//     (write-only) instead of read-modify-writing a uint16 sum (sum_costs, stereo_sgm.h:105-117).
+//     so with P2 <= 255 every direction stores only E -- as G = P2 - E, what the sweeps compute -- as ONE
+//     byte per voxel into its own volume (write-only) instead of read-modify-writing a uint16 sum
+//     (sum_costs, stereo_sgm.h:105-117).
 //     On start pixels L = L_{k-1} + C (stereo_sgm.cc:201,218,236,254) can be larger: they are
-//     image-border pixels, their E byte is 0 and L_{k-1} goes into the small border accumulator SB
+//     image-border pixels, their E is 0 and L_{k-1} goes into the small border accumulator SB
 //     (uint16 ring).  The final kernel rebuilds
-//         S(p,d) = N C(p,d) + sum_k E_k(p,d) (+ SB on border pixels)
+//         S(p,d) = N C(p,d) + sum_k E_k(p,d) (+ SB on border pixels) = N (C + P2) - sum_k G_k (+ SB)
 //     exactly (integers), and does WTA / right-view argmin / LR check / subpixel on it.
-//   HBM bytes per voxel: N (E writes) + N (E reads) = 16 at N = 8, against 41 for the materialised
-//   C + S formulation that the algorithmic-byte model counts.  With that the sweeps are bound by
-//   VALU issue (4 cycles per wave64 instruction), so the mapping minimises instructions per pixel:
+//   HBM bytes per voxel: N (G writes) + N (G reads) = 16 at N = 8, against 41 for the materialised
+//   C + S formulation that the algorithmic-byte model counts.  With that the sweeps run at what a loop of
+//   their VALU work and their stores can write, so the mapping minimises instructions per pixel:
 //
 // Lane mapping ("16 x RP x 2, mirrored"): a pixel's Dp = 32 RP disparities live in ONE 16-lane DPP
 // row; a wave carries 4 pixels -- 4 different paths of the same direction, walked in lock step.
 // Lane q of a row holds RP packed uint16 pairs, register j = ( d = RP q + j , d = Dp-1 - (RP q + j) ):
 // the low halves run upwards from 0, the high halves downwards from Dp-1.
-//   - The recurrence only needs min(L[d-1], L[d+1]); with the mirrored halves that is
-//     pk_min(register j-1, register j+1) for BOTH halves (d-1 of the low half and d+1 of the high
-//     half sit in register j-1, and vice versa), no shuffles inside a lane.
+//   - The recurrence only needs the better of the neighbours d-1 and d+1; with the mirrored halves those are
+//     registers j-1 and j+1 for BOTH halves (d-1 of the low half and d+1 of the high half sit in register
+//     j-1, and vice versa), no shuffles inside a lane.
 //   - "Register -1" is lane q-1's top register (one row_shr DPP; lane 0 has no neighbour on either
-//     half and keeps an INF pair).  "Register RP" is lane q+1's register 0 (one row_shl DPP); in
-//     lane 15 the two halves of the top register (d = Dp/2-1, Dp/2) are each other's neighbours, so
-//     it keeps its own top register with the halves swapped.
-//   - min over d is RP-1 packed mins, a min of the two halves, and 4 row-rotate DPP mins that leave
-//     the minimum in every lane of the row, no scalar round trip.
+//     half).  "Register RP" is lane q+1's register 0 (one row_shl DPP); in lane 15 the two halves of the
+//     top register (d = Dp/2-1, Dp/2) are each other's neighbours, so it keeps its own top register with
+//     the halves swapped.
+//   - The extremum over d is a few packed 3-input operations, one fold of the two halves, and 4 row-rotate
+//     DPP steps that leave it in every lane of the row, no scalar round trip.
+//   Since round 2 the sweeps carry Q = K - L instead of L (bigger is better, maxima instead of minima, the
+//   byte volumes hold G = P2 - E): see aggregate3_kernel.
 //
 // Memory layouts private to this path (d_lo = RP q + j, d_hi = Dp-1 - d_lo):
 //   census left  uint32 [h][w];  census right uint32 [h][wp], wp = Dp + w, pixel x in column Dp + x
 //     (so the RP words censR[x-d] of a lane window are one contiguous in-row load for every x >= 0;
 //      costs with d > x are forced to 255, stereo_sgm.cc:43)
-//   E_k   uint8  [h][w][Dp]     byte 2 (RP q + j) = E(d_lo), byte 2 (RP q + j) + 1 = E(d_hi)
+//   E_k   uint8  [h][w][Dp]     byte 2 (RP q + j) = G(d_lo), byte 2 (RP q + j) + 1 = G(d_hi),  G = P2 - E
 //   BL/SB uint16 [2w+2h][Dp]    uint32 (RP q + j) = ( value(d_lo) , value(d_hi) << 16 )
 #pragma once
 #include "sgmx_kernels.hpp"
