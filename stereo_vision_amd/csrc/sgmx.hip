@@ -419,8 +419,10 @@ template <int RP> hipError_t launch_agg3(bool first, bool pad, dim3 grid, hipStr
 #ifndef SGMX_HZ
 #define SGMX_HZ 1
 #endif
-    if constexpr (SGMX_HZ && RP <= 8) {
-        constexpr int PFH = 8;
+    // (RP = 12, e.g. the 270 disparities of dense_stereo/main.cc:93: 0.58 -> 0.50 ms per launch of 8 KITTI-size pairs;
+    //  RP = 16 gains nothing from it)
+    if constexpr (SGMX_HZ && RP <= 12) {
+        constexpr int PFH = RP <= 8 ? 8 : RP; // a multiple of RP
         if (a.dy == 0 && !first) {
             if (a.dx > 0)
                 return pad ? go(aggregate3_kernel<RP, false, true, PFH, 1>) : go(aggregate3_kernel<RP, false, false, PFH, 1>);

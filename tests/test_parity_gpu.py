@@ -183,13 +183,13 @@ def test_four_paths_with_small_penalties(oracle, case):
         assert np.array_equal(got[j], oracle.sgm_census(left, right, D, wsz, P1, P2, paths)), "pair %d" % j
 
 
-@pytest.mark.parametrize("D", [16, 40, 100, 128, 130, 256])
+@pytest.mark.parametrize("D", [16, 40, 100, 128, 130, 256, 270, 384])
 def test_horizontal_sweep_block_boundaries(oracle, D):
     """The horizontal sweeps keep their census windows in registers and shift them by one word per step, in blocks
-    of 8 steps that need 2 x 8 + 1 pixels of path ahead of them (aggregate3_kernel, HZ): cropped widths around
+    of 8 steps (12 with 257..384 disparities) that need two blocks + 1 pixels of path ahead of them (aggregate3_kernel, HZ): cropped widths around
     every block boundary, disparity ranges of every lane layout with and without pad disparities, three pairs per
     launch so that the 16-lane rows of a wave walk different image rows.  stereo_sgm.cc:191-268."""
-    for w in (15, 16, 17, 18, 19, 24, 25, 26, 27, 33, 34, 35, 41, 42):
+    for w in (15, 16, 17, 18, 19, 24, 25, 26, 27, 33, 34, 35, 37, 38, 41, 42, 49, 50):
         H, W = 11, w + 4
         pairs = [synth_pair(w * 31 + D + k, H, W, max(1, min(D, W // 2))) for k in range(3)]
         e = make(disp_range=D, window_sz=5, penalty1=3, penalty2=60, max_batch=3)
