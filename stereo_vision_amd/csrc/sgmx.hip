@@ -429,6 +429,12 @@ template <int RP> hipError_t launch_agg3(bool first, bool pad, dim3 grid, hipStr
             return pad ? go(aggregate3_kernel<RP, false, true, PFH, -1>) : go(aggregate3_kernel<RP, false, false, PFH, -1>);
         }
     }
+    // diagonal sweeps: w wrapped diagonals of equal length h instead of w + h - 1 diagonals (aggregate3_kernel, WRAP)
+    if (SGMX_WRAP && a.dx != 0 && a.dy != 0) {
+        if (first)
+            return pad ? go(aggregate3_kernel<RP, true, true, PF, 0, true>) : go(aggregate3_kernel<RP, true, false, PF, 0, true>);
+        return pad ? go(aggregate3_kernel<RP, false, true, PF, 0, true>) : go(aggregate3_kernel<RP, false, false, PF, 0, true>);
+    }
     if (first)
         return pad ? go(aggregate3_kernel<RP, true, true, PF>) : go(aggregate3_kernel<RP, true, false, PF>);
     return pad ? go(aggregate3_kernel<RP, false, true, PF>) : go(aggregate3_kernel<RP, false, false, PF>);
@@ -501,7 +507,7 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
         a.dy = np == 8 ? DIRS8[k][1] : DIRS4[k][1];
         a.P1 = c->prm.penalty1;
         a.P2 = c->prm.penalty2;
-        a.npaths = a.dy == 0 ? v.h : (a.dx == 0 ? v.w : v.w + v.h - 1);
+        a.npaths = a.dy == 0 ? v.h : (a.dx == 0 || SGMX_WRAP ? v.w : v.w + v.h - 1); // (wrapped diagonals: w of them)
         a.npairs = n;
         const int nwg = ((a.npaths + 15) / 16) * n; // 4 waves x 4 paths per workgroup
         const dim3 grid(8 * ((nwg + 7) / 8));       // 8 equal XCD chunks

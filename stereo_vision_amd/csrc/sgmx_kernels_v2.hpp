@@ -51,6 +51,9 @@ namespace sgmx {
 #define SGMX_E_AUX 2
 #endif
 constexpr int E_STORE_AUX = SGMX_E_AUX; // cache policy bits of a buffer store: 2 = nt
+#ifndef SGMX_WRAP
+#define SGMX_WRAP 1 // diagonal sweeps walk wrapped diagonals (0: one row per diagonal, A/B builds only)
+#endif
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -239,7 +242,17 @@ __device__ __forceinline__ LaneGeom lane_geometry(int p, int w, int h, int dx, i
 // (one row_shr and one row_shl DPP move), lane 15 hands its own word from one half to the other, and only lane 0
 // takes a word from memory (a 4-byte broadcast load per path and step instead of 2 x 4 RP bytes per lane).  The
 // shifts inside a lane are register renaming once the loop is unrolled RP steps (PF is a multiple of RP here).
-template <int RP, bool FIRST, bool HAS_PAD, int PF, int HZ = 0>
+//
+// WRAP (diagonal sweeps, dx != 0 and dy != 0): a 16-lane row does not walk one diagonal but a "wrapped" one, the pixels
+// (x, y) = ((c + t dx) mod w, y0 + t dy), t = 0 .. h-1, for c = 0 .. w-1 -- diagonal c and then, from the opposite
+// image column on, the diagonal that starts one row further.  That gives w composite paths of the same length h
+// instead of w + h - 1 paths of lengths 1 .. min(w, h): as many equally long waves as a vertical sweep has.  Where a
+// row wraps it does what the reference does at those pixels: the pixel before the wrap ends a path (its L goes into
+// the ring), the pixel after it is a start pixel (L_{k-1} + C from the ring, stereo_sgm.cc:201,236).  Rows of a wave
+// wrap at consecutive steps; those few steps ("zone" zs .. ze below, every w steps) run as the per-lane slow step,
+// everything else as the steady-state loops.  Address streams keep their common per-step stride; a row that wraps
+// moves its voffset by w pixels (the load streams PF steps earlier than the store stream).
+template <int RP, bool FIRST, bool HAS_PAD, int PF, int HZ = 0, bool WRAP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4 : (RP <= 8 ? 3 : 2)))) void aggregate3_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
                                                          uint8_t *__restrict__ E, uint16_t *__restrict__ BL,
                                                          uint16_t *__restrict__ SB, const Agg2Args a)
@@ -277,7 +290,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     // rows past the last path repeat it (same loads, same E bytes) with their ring stores disabled
     const int praw = wave * 4 + (lane >> 4);
     const bool valid = praw < a.npaths;
-    const LaneGeom g = lane_geometry(valid ? praw : a.npaths - 1, w, h, a.dx, a.dy);
+    static_assert(!WRAP || HZ == 0, "wrapped paths are diagonal");
+    LaneGeom g;
+    if constexpr (WRAP) { // composite path c starts in column c of the first image row the sweep visits
+        g.x0 = valid ? praw : a.npaths - 1;
+        g.y0 = a.dy > 0 ? 0 : h - 1;
+        g.len = h;
+        g.edge = false;
+    } else {
+        g = lane_geometry(valid ? praw : a.npaths - 1, w, h, a.dx, a.dy);
+    }
     const int len = g.len;
     int minlen = __builtin_amdgcn_readlane(len, 0), maxlen = minlen, minx = __builtin_amdgcn_readlane(g.x0, 0);
 #pragma unroll
@@ -302,17 +324,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     const unsigned soR0 = sRi < 0 ? T * (unsigned)(-sRi) : 0u, soL0 = sLi < 0 ? T * (unsigned)(-sLi) : 0u,
                    soE0 = sEi < 0 ? T * (unsigned)(-sEi) : 0u;
     const unsigned sR = (unsigned)sRi, sL = (unsigned)sLi, sE = (unsigned)sEi;
+    // WRAP, dx > 0: a row that wraps moves its voffsets DOWN by w pixels; they start this many pixels up (and the
+    // bases as many down) so that no voffset goes below zero: (w + h - 2) / w wraps at most
+    const unsigned wbias = WRAP && a.dx > 0 ? (unsigned)((w + h - 2) / w) * (unsigned)w : 0u;
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(cr + (size_t)pair * (size_t)h * wp) - soR0), 0, -1, 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(cr + (size_t)pair * (size_t)h * wp) - soR0 - (size_t)wbias * 4), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(cl + (size_t)pair * npix) - soL0), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsE =
-        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(E + (size_t)pair * npix * Dp) - soE0, 0, -1, 0x00020000);
-    // lane parts: start pixel of the lane's path + its window / line slice
-    const unsigned voRl = (unsigned)((g.y0 * wp + Dp + g.x0 - RP * q - (RP - 1)) * 4); // low-half window
-    const unsigned voRh = (unsigned)((g.y0 * wp + g.x0 + 1 + RP * q) * 4);             // high-half window
-    const unsigned voL = (unsigned)((g.y0 * w + g.x0) * 4);
-    const unsigned voE = (unsigned)((g.y0 * w + g.x0) * Dp + 2 * RP * q);
+        const_cast<char *>(reinterpret_cast<const char *>(cl + (size_t)pair * npix) - soL0 - (size_t)wbias * 4), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(E + (size_t)pair * npix * Dp) - soE0 - (size_t)wbias * Dp, 0, -1, 0x00020000);
+    // lane parts: start pixel of the lane's path + its window / line slice (WRAP: moved when the row wraps)
+    unsigned voRl = (unsigned)((g.y0 * wp + Dp + g.x0 - RP * q - (RP - 1)) * 4) + wbias * 4; // low-half window
+    unsigned voRh = (unsigned)((g.y0 * wp + g.x0 + 1 + RP * q) * 4) + wbias * 4;             // high-half window
+    unsigned voL = (unsigned)((g.y0 * w + g.x0) * 4) + wbias * 4;
+    unsigned voE = (unsigned)((g.y0 * w + g.x0) * Dp + 2 * RP * q) + wbias * Dp;
+    // WRAP: what a wrap adds to a voffset (one image row of pixels back or forth), and the row's column at step 0
+    // "unwrapped" (column at step t = x0 + t dx): x0e for the step being computed, x0p for the step being prefetched
+    const unsigned wrapR = (unsigned)(-a.dx * w * 4), wrapE = (unsigned)(-a.dx * w * Dp);
+    int x0e = g.x0, x0p = g.x0;
+    const int xend = a.dx > 0 ? w - 1 : 0; // WRAP: the column where a diagonal ends
     const size_t ring = (size_t)(2 * w + 2 * h) * (Dp / 2); // uint32 units
     // Paths along an image edge write L of every pixel into the ring.  Away from the corners (steps
     // 1 .. len-2) the ring slot is linear in the step, so the steady-state loop stores through a
@@ -328,8 +358,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     u32 *SBf = reinterpret_cast<u32 *>(SB) + (size_t)pair * ring + RP * q;
 
     const u32 P1p = (u32)a.P1 * 0x10001u, P2p = (u32)a.P2 * 0x10001u;
-    const int tl0 = g.x0 - RP * q;          // x - RP q at step 0
-    const int th0 = Dp - 1 - RP * q - g.x0; // Dp-1 - RP q - x at step 0
+    int tl0 = g.x0 - RP * q;          // x - RP q at step 0 (WRAP: of the unwrapped column)
+    int th0 = Dp - 1 - RP * q - g.x0; // Dp-1 - RP q - x at step 0
     u32 padfloor[RP], padmask[RP];
 #pragma unroll
     for (int j = 0; j < RP; j++) {
@@ -408,14 +438,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < PF; i++)
+        for (int i = 0; i < PF; i++) {
+            if constexpr (WRAP) { // a row whose step 1 + i lies past the image column it ends in continues w pixels back
+                const int xp = x0p + (1 + i) * a.dx;
+                if (a.dx > 0 ? xp >= w : xp < 0) {
+                    x0p -= a.dx * w;
+                    voRl += wrapR;
+                    voRh += wrapR;
+                    voL += wrapR;
+                }
+            }
             if (1 + i < len) {
                 buf_load_win<RP>(rsR, voRl, soR0 + (1 + i) * sR, qwl[i]);
                 buf_load_win<RP>(rsR, voRh, soR0 + (1 + i) * sR, qwh[i]);
                 qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soL0 + (1 + i) * sL, 0);
             }
+        }
     }
-    u32 *bl_last = BLf + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
+    u32 *bl_last = nullptr; // the ring slot of the path's last pixel
+    if constexpr (!WRAP)
+        bl_last = BLf + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
 
     unsigned soRp = soR0 + (1 + PF) * sR, soLp = soL0 + (1 + PF) * sL; // soffsets of the step PF ahead
     unsigned soE = soE0, soB = soB0;
@@ -424,6 +466,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         constexpr bool SLOW = decltype(slowc)::value, EDGE = decltype(edgec)::value, GUARD = decltype(guardc)::value;
         soE += sE;
         soB += sB;
+        // WRAP, slow steps: does this row start a new diagonal at step t (the column after the one diagonals end in),
+        // and is its pixel the last of a diagonal (its L goes into the ring)?  Both are border pixels.
+        bool wstart = false, wend = false;
+        int xt = 0;
+        if constexpr (WRAP && SLOW) {
+            xt = x0e + t * a.dx;
+            if (a.dx > 0 ? xt >= w : xt < 0) {
+                x0e -= a.dx * w;
+                xt -= a.dx * w;
+                tl0 -= a.dx * w;
+                th0 += a.dx * w;
+                voE += wrapE;
+                wstart = true;
+            }
+            wend = xt == xend || t == len - 1;
+        }
         u32 wl[RP], wh[RP];
 #pragma unroll
         for (int j = 0; j < RP; j++) {
@@ -461,7 +519,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
                     qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
                 if ((!SLOW && !GUARD) || t + PF + 1 < len) // (fast blocks end two blocks and a step before the path does)
                     qnw[i] = __builtin_amdgcn_raw_buffer_load_b32(rsR, voN, soRp + sR, 0);
-            } else
+            } else {
+            if constexpr (WRAP && (SLOW || GUARD)) { // (fast blocks end before any row's prefetch target wraps)
+                const int xp = x0p + (t + PF) * a.dx;
+                if (a.dx > 0 ? xp >= w : xp < 0) {
+                    x0p -= a.dx * w;
+                    voRl += wrapR;
+                    voRh += wrapR;
+                    voL += wrapR;
+                }
+            }
 #ifdef SGMX_EXP_NOLOAD // timing-only build (wrong results): the steady-state loops without their census loads
             if (SLOW && t + PF < len) {
 #else
@@ -470,6 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
                 buf_load_win<RP>(rsR, voRl, soRp, qwl[i]);
                 buf_load_win<RP>(rsR, voRh, soRp, qwh[i]);
                 qcl[i] = __builtin_amdgcn_raw_buffer_load_b32(rsL, voL, soLp, 0);
+            }
             }
 #ifndef SGMX_EXP_FIXLOAD // (defined: timing-only, every step loads the census words of the path's first pixels again)
             soRp += sR;
@@ -509,12 +577,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         if (MASK) {
             u32 c[RP];
             cost_from_census<RP, true>(wl, wh, clv, tl0 + t * a.dx, th0 - t * a.dx, c);
+            u32 bl[RP] = {};
+            if constexpr (WRAP && SLOW && !FIRST) {
+                if (wstart) { // start pixel: L_k = L_{k-1} + C, the carry L_{k-1} goes to SB (as in step 0)
+                    const size_t bo = (size_t)border_index(g.y0 + t * a.dy, xt, w, h) * (Dp / 2);
+                    u32 sb[RP];
+                    __builtin_memcpy(bl, BLf + bo, 4 * RP);
+                    __builtin_memcpy(sb, SBf + bo, 4 * RP);
+#pragma unroll
+                    for (int j = 0; j < RP; j++)
+                        sb[j] = pk_add(sb[j], bl[j]);
+                    if (valid)
+                        __builtin_memcpy(SBf + bo, sb, 4 * RP);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < RP; j++) {
                 Lv[j] = pk_add(pk_sub(P2p, e[j]), c[j]);
+                if (WRAP && SLOW && wstart) {
+                    Lv[j] = pk_add(bl[j], c[j]);
+                    e[j] = P2p; // E = 0 on start pixels
+                }
                 if (HAS_PAD)
                     Lv[j] = pk_max(Lv[j], padfloor[j]);
-                prior[j] = pk_sub_sat(KMp, Lv[j]);
+                prior[j] = pk_sub_sat(WRAP && SLOW && wstart ? 0x70007000u : KMp, Lv[j]);
             }
         } else {
             // Q = G + (32 - C): 32 - popcount(x) = popcount(~x), the add folded into the popcount (v_bcnt
@@ -573,7 +659,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         } else if (t < len) {
             buf_store_ev<RP>(rsE, voE, soE, eb);
             if (valid) {
-                if (g.edge) // path along an image edge: every pixel feeds a later direction's start
+                if constexpr (WRAP) {
+                    if (wstart || wend) // first or last pixel of a diagonal
+                        __builtin_memcpy(BLf + (size_t)border_index(g.y0 + t * a.dy, xt, w, h) * (Dp / 2), Lv, 4 * RP);
+                } else if (g.edge) // path along an image edge: every pixel feeds a later direction's start
                     __builtin_memcpy(BLf + (size_t)border_index(g.y0 + t * a.dy, g.x0 + t * a.dx, w, h) * (Dp / 2), Lv, 4 * RP);
                 else if (t == len - 1)
                     __builtin_memcpy(bl_last, Lv, 4 * RP);
@@ -589,23 +678,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     // A run of full blocks of one kind is a loop of its own: sharing one loop between the kinds made the
     // compiler copy the whole prefetch ring and drain vmcnt in every block.
     int t = 1;
+    // WRAP: zs .. ze = the steps at which the rows of this wave wrap next (the row with the column nearest the end
+    // column first); the step before each is the last pixel of a diagonal.  lim = the step the steady-state loops
+    // stop short of: a path end, or the next wrap.
+    int zs = 0x7fffffff, ze = 0x7fffffff, lim = minlen;
+    if constexpr (WRAP) {
+        const int c0 = __builtin_amdgcn_readlane(g.x0, 0), c3 = __builtin_amdgcn_readlane(g.x0, 48);
+        zs = a.dx > 0 ? w - c3 : c0 + 1;
+        ze = a.dx > 0 ? w - c0 : c3 + 1;
+        lim = zs < len ? zs : len;
+    }
     auto run = [&](auto maskc, auto edgec) {
         do {
 #pragma unroll
             for (int i = 0; i < PF; i++)
                 step(maskc, BoolC<false>(), edgec, BoolC<false>(), t + i, i);
             t += PF;
-        } while (t + 2 * PF + (HZ ? 1 : 0) <= minlen && unmasked(t) != decltype(maskc)::value);
+        } while (t + 2 * PF + (HZ ? 1 : 0) <= lim && unmasked(t) != decltype(maskc)::value);
     };
     while (t < maxlen) {
-        if (t + 2 * PF + (HZ ? 1 : 0) <= minlen) { // every row: steps t..t+PF-1 and their prefetch targets exist, none is last
+        if constexpr (WRAP) {
+            while (ze < t) { // every row has wrapped: on to the next zone, w steps later, with all columns w further back
+                zs += w;
+                ze += w;
+                minx -= a.dx * w;
+            }
+            lim = zs < len ? zs : len;
+        }
+        if (t + 2 * PF + (HZ ? 1 : 0) <= lim) { // every row: steps t..t+PF-1 and their prefetch targets exist, none is last
             if (!unmasked(t))
                 run(BoolC<true>(), BoolC<true>());
             else if (any_edge)
                 run(BoolC<false>(), BoolC<true>());
             else
                 run(BoolC<false>(), BoolC<false>());
-        } else if (t + PF < minlen && !any_edge && unmasked(t)) {
+        } else if (WRAP && t + PF < lim) {
+            // blocks before a wrap or the end: no step of theirs is a diagonal's first or last one, but what they
+            // prefetch may lie past the wrap (the row's load voffsets move there) or past the end
+            if (unmasked(t)) {
+#pragma unroll
+                for (int i = 0; i < PF; i++)
+                    step(BoolC<false>(), BoolC<false>(), BoolC<false>(), BoolC<true>(), t + i, i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PF; i++)
+                    step(BoolC<true>(), BoolC<false>(), BoolC<false>(), BoolC<true>(), t + i, i);
+            }
+            t += PF;
+        } else if (!WRAP && t + PF < minlen && !any_edge && unmasked(t)) {
             // the last full blocks of the paths: none of their steps is a row's last one, but what they prefetch
             // may lie past a path's end -- the steady-state steps with guarded loads
 #pragma unroll
