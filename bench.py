@@ -132,6 +132,113 @@ def secondary_figures(eng, sv, args, Lh, Rh, B, W, H):
     return sec
 
 
+def other_configs(sv, torch, device):
+    """The other BASELINE.json configurations, timed in the same process after the headline (never `value`): inputs
+    resident in HBM, HIP-event kernel times from the engine's own profiling hooks.
+      float_volume  -- configs[3]: precomputed float data-cost volumes 1241x376x128 through recon::SGM's aggregation
+                       (sgm.cc:103-118,177-254), 8 volumes per step; bytes = SURVEY.md 8d's 96 B/voxel model
+      uhd_4k        -- configs[4]: 3840x2160, D=256, 8 paths, 8 pairs per call (the call runs them as launches of 3+3+2)
+      tsukuba_4path -- configs[0]'s geometry on the GPU: 384x288, D=16, 4 paths, 64 pairs per step"""
+    out = {}
+
+    def timed(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps
+
+    def kernel_ms(eng, steps):
+        return {k: round(v[0] / steps, 4) for k, v in eng.kernel_stats().items() if v[1]}
+
+    # ---- float data-cost volumes
+    H, W, D, B, N = 376, 1241, 128, 8, 8
+    g = torch.Generator(device="cuda").manual_seed(7)
+    Cv = (torch.rand((B, H, W, D), device="cuda", generator=g) * 4).contiguous()
+    do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
+    e = sv.SGM(sv.SGMParams(disp_range=D, penalty1=3, penalty2=60, device=device, max_batch=B))
+    fn = lambda: e.compute_cost_device(Cv.data_ptr(), do.data_ptr(), B, W, H, 0)
+    timed(fn, 1, 2)
+    e.set_profiling(True)
+    steps = 10
+    dt = timed(fn, steps, 0)
+    dirs = e.direction_stats()
+    km = kernel_ms(e, steps)
+    e.set_profiling(False)
+    V = H * W * D
+    sweep_ms = sum(d[0] for d in dirs) / max(1, sum(d[1] for d in dirs))
+    sweep_bytes = V * B * (12 * N - 4) / N  # C read once per sweep; S written by the first sweep, read-modify-written by the others
+    out["float_volume"] = {
+        "workload": "float data-cost volumes %dx%dx%d, %d paths, P1=3, P2=60, %d volumes per step" % (W, H, D, N, B),
+        "volumes_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "dtype": "f32",
+        "model_bytes_per_voxel": 12 * N, "step_GBs": round(12 * N * V * B / dt / 1e9, 1),
+        "step_frac_of_peak": round(12 * N * V * B / dt / 1e9 / HBM_PEAK_GBS, 4),
+        "sweep": {"kernel": "aggregate_f32_kernel", "avg_launch_ms": round(sweep_ms, 4), "alg_bytes_per_launch": int(sweep_bytes),
+                  "achieved": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                  "frac": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "per_direction_ms": [round(d[0] / max(1, d[1]), 4) for d in dirs]},
+        "kernel_ms_per_step": km}
+    e.close()
+    del Cv, do, e
+    torch.cuda.empty_cache()
+
+    # ---- 3840x2160, D = 256
+    H, W, D, B = 2160, 3840, 256, 8
+    pairs = [synthetic_pair(7 + i, H, W, 240) for i in range(2)]
+    L = torch.from_numpy(np.stack([pairs[i % 2][0] for i in range(B)])).cuda()
+    R = torch.from_numpy(np.stack([pairs[i % 2][1] for i in range(B)])).cuda()
+    do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
+    e = sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=5, penalty1=3, penalty2=60, device=device, max_batch=B))
+    fn = lambda: e.compute_device(L.data_ptr(), R.data_ptr(), do.data_ptr(), B, W, H, 0)
+    timed(fn, 1, 1)
+    e.set_profiling(True)
+    steps = 4
+    dt = timed(fn, steps, 0)
+    dirs = e.direction_stats()
+    km = kernel_ms(e, steps)
+    e.set_profiling(False)
+    h_, w_, Dp = H - 4, W - 4, 256
+    pair_bytes = h_ * w_ * Dp + h_ * w_ * 4 + h_ * (w_ + Dp) * 4 + 4 * (2 * w_ + 2 * h_) * Dp * 2  # as `roofline` below
+    sweeps_ms = sum(d[0] for d in dirs) / steps  # all sweeps of one step (8 pairs)
+    out["uhd_4k"] = {
+        "workload": "census/Hamming SGM %dx%d, D=%d, 8 paths, wsz=5, P1=3, P2=60, %d pairs per call" % (W, H, D, B),
+        "frames_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 2), "mde_per_s": round(B / dt * W * H * D / 1e6, 1),
+        "dtype": "u16",
+        "sweep": {"kernel": "aggregate3_kernel", "per_direction_ms_per_%d_pairs" % B: [round(d[0] / steps, 3) for d in dirs],
+                  "launches_per_direction_per_step": dirs[0][1] // steps,
+                  "alg_bytes_per_direction": int(B * pair_bytes),
+                  "achieved": round(8 * B * pair_bytes / (sweeps_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                  "frac": round(8 * B * pair_bytes / (sweeps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "kernel_ms_per_step": km}
+    e.close()
+    del L, R, do, e
+    torch.cuda.empty_cache()
+
+    # ---- Tsukuba geometry, 4 paths
+    H, W, D, B = 288, 384, 16, 64
+    pairs = [synthetic_pair(3 + i, H, W, 12) for i in range(4)]
+    L = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).cuda()
+    R = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).cuda()
+    do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
+    e = sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=5, penalty1=3, penalty2=60, num_paths=4, device=device, max_batch=B))
+    fn = lambda: e.compute_device(L.data_ptr(), R.data_ptr(), do.data_ptr(), B, W, H, 0)
+    timed(fn, 1, 3)
+    e.set_profiling(True)
+    steps = 50
+    dt = timed(fn, steps, 0)
+    km = kernel_ms(e, steps)
+    e.set_profiling(False)
+    out["tsukuba_4path"] = {
+        "workload": "census/Hamming SGM %dx%d, D=%d, 4 paths, wsz=5, P1=3, P2=60, %d pairs per step" % (W, H, D, B),
+        "frames_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mde_per_s": round(B / dt * W * H * D / 1e6, 1),
+        "dtype": "u16", "kernel_ms_per_step": km}
+    e.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,9 +260,12 @@ def main():
                     "ranks on one device: use it with --backend gloo)")
     ap.add_argument("--dist-always", action="store_true", help="initialise the process group, barrier and all-reduce "
                     "even with one rank (exercises the RCCL leg on a one-GPU box)")
-    ap.add_argument("--min-seconds", type=float, default=0.0, help="repeat the K timed steps until the timed region "
-                    "lasts this long (reported steps = what ran); 0 = exactly --steps")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (single pair, host batch)")
+    ap.add_argument("--min-seconds", type=float, default=None, help="floor on the timed region: the block of --steps steps "
+                    "is repeated (`timed_blocks` whole blocks, same count on every rank) until it lasts this long.  Default: "
+                    "0 with one rank (exactly --steps steps), 2 s with several (a short region there is mostly barrier jitter)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (single pair, host batch, "
+                    "the other BASELINE configurations)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the float-volume / 4K / Tsukuba legs of `secondary`")
     args = ap.parse_args()
 
     import torch
@@ -206,31 +316,43 @@ def main():
     fence()
     eng.kernel_stats()  # clear
     eng.set_profiling(not args.no_events)
-    steps = args.steps
-    if args.min_seconds > 0:  # same count on every rank: estimated from rank 0's warm-up-sized probe
+    # The timed region is `blocks` whole blocks of --steps steps.  One rank: one block, exactly --steps steps.  Several
+    # ranks: as many blocks as last min_seconds (2 s by default), the same count on every rank, estimated from the
+    # slowest rank's probe step -- --steps steps of 6 ms are mostly barrier jitter at N = 8.
+    dev_t = "cuda" if (use_dist and args.backend == "nccl") else "cpu"
+    min_seconds = args.min_seconds if args.min_seconds is not None else (2.0 if world > 1 else 0.0)
+    blocks = 1
+    if min_seconds > 0:
         tp = time.perf_counter()
         step()
         fence()
-        est = torch.tensor([time.perf_counter() - tp], dtype=torch.float64,
-                           device="cuda" if (use_dist and args.backend == "nccl") else "cpu")
+        est = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev_t)
         if use_dist:
             dist.all_reduce(est, op=dist.ReduceOp.MAX)
-        steps = max(args.steps, int(args.min_seconds / max(float(est.item()), 1e-6)) + 1)
+        blocks = max(1, -(-int(min_seconds / max(float(est.item()), 1e-6) + 1) // args.steps))
         eng.kernel_stats()
+    steps = args.steps * blocks
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0  # this rank's own steps, before it waits for the others
     fence()
     dt = time.perf_counter() - t0
+    dirs = eng.direction_stats()
     stats = eng.kernel_stats()
     eng.set_profiling(False)
+    per_rank_fps = [round(B * steps / dt_own, 2)]
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    args.steps = steps
+        own = torch.tensor([dt_own], dtype=torch.float64, device=dev_t)
+        allr = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(allr, own)
+        per_rank_fps = [round(B * steps / float(x.item()), 2) for x in allr]
 
-    frames = world * B * args.steps
+    frames = world * B * steps
     fps = frames / dt
     m = (args.wsz - 1) // 2
     V = (W - 2 * m) * (H - 2 * m) * D
@@ -243,8 +365,10 @@ def main():
         "mde_per_s": round(fps * W * H * D / 1e6, 1),
         "n_gpus": world,
         "steps": args.steps,
+        "timed_blocks": blocks,  # the timed region = timed_blocks x steps steps (1 unless --min-seconds / several ranks)
         "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "ms_per_step": round(dt / steps * 1e3, 4),
+        "per_rank_fps": per_rank_fps,  # each rank's own steps / its own time, before the closing barrier
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -272,7 +396,7 @@ def main():
             Dp = 32 * (1 if D <= 32 else 2 if D <= 64 else 4 if D <= 128 else 8 if D <= 256 else 12 if D <= 384 else 16)
             # pairs per kernel launch: B, unless the engine runs the call as several launches (more than 32 pairs or
             # more than 208 MB of census images per launch: DESIGN.md 4)
-            ppl = B * args.paths * args.steps / agg_n
+            ppl = B * args.paths * steps / agg_n
             model_bytes = ppl * alg_agg / args.paths
             if fast:
                 launch_bytes = ppl * (h_ * w_ * Dp + h_ * w_ * 4 + h_ * (w_ + Dp) * 4 + 4 * (2 * w_ + 2 * h_) * Dp * 2)
@@ -306,9 +430,10 @@ def main():
                     "model_bytes_per_launch": model_bytes,
                     "model_bytes_equiv_GBs": round(model_bytes / avg_s / 1e9, 1),
                     "step_hbm_bytes_from_pmc": step_bytes,
-                    "step_hbm_GBs": round(step_bytes / (dt / args.steps) / 1e9, 1) if step_bytes else None,
-                    "step_hbm_frac_of_peak": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if step_bytes else None,
-                    "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stats.items()}}
+                    "step_hbm_GBs": round(step_bytes / (dt / steps) / 1e9, 1) if step_bytes else None,
+                    "step_hbm_frac_of_peak": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4) if step_bytes else None,
+                    "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in stats.items()},
+                    "per_direction_ms": [round(d[0] / max(1, d[1]), 4) for d in dirs]}
         out["roofline"] = roof
 
         cpu = None
@@ -342,6 +467,11 @@ def main():
         out["cpu_baseline"] = cpu
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_figures(eng, sv, args, Lh, Rh, B, W, H)
+            if not args.no_other_configs:
+                eng.close()
+                del dL, dR, dO
+                torch.cuda.empty_cache()
+                out["secondary"].update(other_configs(sv, torch, local_rank))
         print(json.dumps(out), flush=True)
 
     if use_dist:

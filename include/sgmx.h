@@ -302,6 +302,10 @@ enum {
  * launch count of one kernel class and clears them. */
 SGMX_API int sgmx_set_profiling(sgmx_ctx *ctx, int enabled);
 SGMX_API int sgmx_kernel_stats(sgmx_ctx *ctx, int kernel_class, double *total_ms, long *launches);
+/* The SGMX_K_AGGREGATE time again, split by direction: k = index of the direction in the schedule (8 paths: the
+ * order of stereo_sgm.cc:120-122, (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1) as (DIRX, DIRY); 4 paths:
+ * its axis-aligned subset).  Same semantics as sgmx_kernel_stats: synchronises, returns and clears. */
+SGMX_API int sgmx_direction_stats(sgmx_ctx *ctx, int k, double *total_ms, long *launches);
 
 /* Algorithmic HBM bytes of one pair on the census path, B = V*(5N+1) + 10*W*H
  * (SURVEY.md 8d), and of its aggregation launches alone, 5*N*V - 2*V. */

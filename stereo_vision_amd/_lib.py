@@ -60,6 +60,7 @@ SYMBOLS = {
     "sgmx_get_data_cost_wta_u8": (_i, [_vp, _i, _vp]),
     "sgmx_set_profiling": (_i, [_vp, _i]),
     "sgmx_kernel_stats": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "sgmx_direction_stats": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "sgmx_algorithmic_bytes_census": (C.c_double, [_vp, _i, _i, C.POINTER(C.c_double)]),
 }
 

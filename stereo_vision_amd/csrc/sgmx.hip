@@ -31,6 +31,7 @@ const int DIRS_NS[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}, {
 
 struct ProfRec {
     int cls;
+    int dir; // direction sweeps: index of the direction in the schedule, else -1
     hipEvent_t a, b;
 };
 
@@ -132,6 +133,8 @@ struct sgmx_ctx {
     std::vector<ProfRec> prof;
     double prof_ms[SGMX_K_COUNT] = {0};
     long prof_n[SGMX_K_COUNT] = {0};
+    double prof_dir_ms[16] = {0}; // the sweeps again, per direction of the schedule
+    long prof_dir_n[16] = {0};
 };
 
 namespace {
@@ -265,10 +268,11 @@ struct ProfScope {
     hipStream_t st;
     ProfRec r;
     bool on;
-    ProfScope(sgmx_ctx *c_, int cls, hipStream_t s) : c(c_), st(s), on(c_->profiling)
+    ProfScope(sgmx_ctx *c_, int cls, hipStream_t s, int dir = -1) : c(c_), st(s), on(c_->profiling)
     {
         if (on) {
             r.cls = cls;
+            r.dir = dir;
             on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess;
             if (on)
                 (void)hipEventRecord(r.a, st);
@@ -343,7 +347,7 @@ int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st, const void *Cv
         a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
         a.first = k == 0;
         const dim3 grid((a.npaths + 3) / 4, n);
-        ProfScope ps(c, SGMX_K_AGGREGATE, st);
+        ProfScope ps(c, SGMX_K_AGGREGATE, st, k);
         if (f32)
             launch_agg<true>(c->R, k == 0, c->prm.disp_range != c->Dp, a, grid, st);
         else
@@ -513,7 +517,7 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
         const dim3 grid(8 * ((nwg + 7) / 8));       // 8 equal XCD chunks
         const size_t lds = 0;
         uint8_t *Ek = v.E + (size_t)k * v.bytes_E * v.cap;
-        ProfScope ps(c, SGMX_K_AGGREGATE, st);
+        ProfScope ps(c, SGMX_K_AGGREGATE, st, k);
         hipError_t le;
         if (c->RP == 1)
             le = launch_agg3<1>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
@@ -1965,10 +1969,9 @@ int sgmx_set_profiling(sgmx_ctx *c, int enabled)
     return SGMX_OK;
 }
 
-int sgmx_kernel_stats(sgmx_ctx *c, int cls, double *total_ms, long *launches)
+// Synchronise and fold the recorded event pairs into the per-class and per-direction sums.
+static int collect_profile(sgmx_ctx *c)
 {
-    if (!c || cls < 0 || cls >= SGMX_K_COUNT)
-        return fail(c, SGMX_ERR_INVALID_ARG, "bad kernel class");
     HIPCHK(c, hipSetDevice(c->prm.device));
     HIPCHK(c, hipDeviceSynchronize());
     for (auto &r : c->prof) {
@@ -1976,11 +1979,41 @@ int sgmx_kernel_stats(sgmx_ctx *c, int cls, double *total_ms, long *launches)
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             c->prof_ms[r.cls] += ms;
             c->prof_n[r.cls] += 1;
+            if (r.dir >= 0 && r.dir < 16) {
+                c->prof_dir_ms[r.dir] += ms;
+                c->prof_dir_n[r.dir] += 1;
+            }
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     c->prof.clear();
+    return SGMX_OK;
+}
+
+int sgmx_direction_stats(sgmx_ctx *c, int k, double *total_ms, long *launches)
+{
+    if (!c || k < 0 || k >= 16)
+        return fail(c, SGMX_ERR_INVALID_ARG, "bad direction index");
+    const int rc = collect_profile(c);
+    if (rc)
+        return rc;
+    if (total_ms)
+        *total_ms = c->prof_dir_ms[k];
+    if (launches)
+        *launches = c->prof_dir_n[k];
+    c->prof_dir_ms[k] = 0;
+    c->prof_dir_n[k] = 0;
+    return SGMX_OK;
+}
+
+int sgmx_kernel_stats(sgmx_ctx *c, int cls, double *total_ms, long *launches)
+{
+    if (!c || cls < 0 || cls >= SGMX_K_COUNT)
+        return fail(c, SGMX_ERR_INVALID_ARG, "bad kernel class");
+    const int rc = collect_profile(c);
+    if (rc)
+        return rc;
     if (total_ms)
         *total_ms = c->prof_ms[cls];
     if (launches)

@@ -82,6 +82,15 @@ class Engine:
             out[name] = (ms.value, n.value)
         return out
 
+    def direction_stats(self):
+        """[(total ms, launches)] of the direction sweeps since the last call, in schedule order."""
+        out = []
+        for k in range(self.params.num_paths):
+            ms, n = C.c_double(), C.c_long()
+            self.check(self.lib.sgmx_direction_stats(self.h, k, C.byref(ms), C.byref(n)))
+            out.append((ms.value, n.value))
+        return out
+
     def algorithmic_bytes(self, W, H):
         agg = C.c_double()
         tot = self.lib.sgmx_algorithmic_bytes_census(self.h, W, H, C.byref(agg))

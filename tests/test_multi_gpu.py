@@ -43,6 +43,10 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["dist_backend"] == "gloo"
     # whole-job figure: both ranks' pairs over the slower rank's time
     assert abs(out["value"] - 2 * 4 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"] + 0.1
+    # several ranks: `steps` stays what was asked for, the timed region is timed_blocks whole blocks of it (2 s floor),
+    # and every rank's own rate is in the line
+    assert out["steps"] == 3 and out["timed_blocks"] >= 1 and len(out["per_rank_fps"]) == 2
+    assert all(f >= out["value"] / 2 * 0.999 for f in out["per_rank_fps"])  # no rank is slower than the job's per-rank share
 
 
 def test_sgm_batch_two_workers_equal_one_at_kitti_size(tmp_path):

@@ -199,6 +199,38 @@ def test_horizontal_sweep_block_boundaries(oracle, D):
         e.close()
 
 
+@pytest.mark.parametrize("shape", [(40, 3840), (2160, 64)], ids=["3840x40", "64x2160"])
+def test_4k_geometry_strips_vs_oracle(oracle, shape):
+    """BASELINE.json configs[4]'s geometry (3840x2160, D=256, 8 paths) in strips the oracle finishes in seconds: a
+    3840-wide strip (horizontal paths of 3 836 steps: the shift-register blocks, the launch split; diagonals that wrap
+    after 36 rows) and a 2160-tall strip (vertical paths of 2 156 steps, diagonals that wrap every 60 rows), at RP = 8,
+    three pairs per launch.  Final disparity against the oracle.  stereo_sgm.cc:120-135,191-268."""
+    H, W = shape
+    D = 256
+    pairs = [synth_pair(4000 + H + k, H, W, min(240, W // 2)) for k in range(3)]
+    e = make(disp_range=D, window_sz=5, penalty1=3, penalty2=60, max_batch=3)
+    got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+    e.close()
+    for k, (left, right) in enumerate(pairs):
+        assert np.array_equal(got[k], oracle.sgm_census(left, right, D, 5, 3, 60, 8)), "pair %d" % k
+
+
+@pytest.mark.parametrize("D", [16, 128, 256, 270])
+def test_wrapped_diagonal_boundaries(oracle, D):
+    """The diagonal sweeps walk wrapped diagonals (aggregate3_kernel, WRAP): a 16-lane row continues, after the image
+    column its diagonal ends in, with the diagonal that starts one row further, in steady-state blocks that stop short
+    of the wrap.  Cropped widths and heights around the block sizes, wider than tall, square, and taller than wide
+    (several wraps per row), three pairs per launch.  stereo_sgm.cc:197-267 (start sets), stereo_sgm.h:119-147."""
+    for w, h in ((9, 9), (10, 9), (9, 10), (13, 30), (16, 33), (17, 17), (18, 70), (23, 8), (31, 12), (40, 41), (3, 20), (2, 9), (1, 7)):
+        H, W = h + 4, w + 4
+        pairs = [synth_pair(w * 37 + h * 5 + D + k, H, W, max(1, min(D, W // 2))) for k in range(3)]
+        e = make(disp_range=D, window_sz=5, penalty1=3, penalty2=60, max_batch=3)
+        got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+        for k, (left, right) in enumerate(pairs):
+            assert np.array_equal(got[k], oracle.sgm_census(left, right, D, 5, 3, 60, 8)), "w=%d h=%d pair %d" % (w, h, k)
+        e.close()
+
+
 @pytest.mark.parametrize("case", _random_configs(64, 777), ids=lambda c: "x".join(map(str, c)))
 def test_seeded_random_configurations_three_pairs(oracle, case):
     """A second seeded draw (the one exp/random_stress.py starts with), three different pairs per launch: the four
