@@ -239,6 +239,63 @@ def other_configs(sv, torch, device):
     return out
 
 
+def hamming_library_leg(sv, device, na=100000, nb=4096, ncodes=16, ht=44):
+    """core/hamming.h's set functions at na x nb signatures of ncodes bytes through the C ABI (host buffers in, host
+    buffers out: these entry points have no device-resident form, core/hamming.h:62-112 has none either), next to the
+    reference's own core/hamming.c (oracle/_ref/libhamming_ref.so, built from the reference tree where it lies) on the
+    box's host cores -- the one place where the CPU baseline IS the reference's compiled code (kind "reference").
+    Matrix: 2 na nb bytes out; write-bound on the GPU, PCIe-bound end to end."""
+    from oracle import oracle as o
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, size=(na, ncodes)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(nb, ncodes)).astype(np.uint8)
+    e = sv.StereoSGM(sv.StereoSGMParams(device=device))
+    out = {"workload": "%d x %d signatures of %d bytes, threshold %d" % (na, nb, ncodes, ht)}
+
+    def gpu(fn, reps=3):
+        fn()  # (sizes the context's buffers)
+        e.kernel_stats()
+        e.set_profiling(True)
+        t = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        dt = (time.perf_counter() - t) / reps
+        ms, n = e.kernel_stats()["hamming_library"]
+        e.set_profiling(False)
+        return r, dt, ms / reps
+
+    dis, dt, kms = gpu(lambda: e.hamming_matrix(a, b))
+    mbytes = 2.0 * na * nb
+    out["matrix"] = {"entry": "sgmx_hamming_matrix_u16 (compute_hamming, core/hamming.c:215-236)",
+                     "kernel_ms": round(kms, 4), "bytes_out": int(mbytes), "kernel_GBs": round(mbytes / (kms * 1e-3) / 1e9, 1),
+                     "kernel_frac_of_peak": round(mbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "write_bound_ms_at_6300_GBs": round(mbytes / 6.3e12 * 1e3, 4),
+                     "end_to_end_ms": round(dt * 1e3, 2), "end_to_end_note": "pageable host buffers; the %d MB matrix crosses PCIe" % (mbytes / 1e6)}
+    (idx, hams), dt, kms = gpu(lambda: e.match_hamming_thres(a, b, ht))
+    out["match"] = {"entry": "sgmx_match_hamming_count + sgmx_match_hamming_thres_prealloc (core/hamming.c:300-322, 725-765)",
+                    "matches": int(len(hams)), "kernel_ms_count_plus_emit": round(kms, 4), "end_to_end_ms": round(dt * 1e3, 2),
+                    "pairs_per_s_end_to_end": round(na * nb / dt, 0)}
+    e.close()
+    ncore = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "0")) or 10 ** 6)
+    t = time.perf_counter()
+    rdis = o.ref_hamming_matrix_thread(a, b)
+    t_thread = time.perf_counter() - t
+    if rdis is None:
+        out["cpu_reference"] = None  # oracle/_ref not built (no reference tree where this tree was built)
+        return out
+    t = time.perf_counter()
+    ridx, rhams = o.ref_match_hamming(a, b, ht)
+    t_match = time.perf_counter() - t
+    out["cpu_reference"] = {
+        "kind": "reference", "library": "oracle/_ref/libhamming_ref.so = the reference's core/hamming.c, gcc -O2 -msse4.2 -fopenmp",
+        "compute_hamming_thread_ms": round(t_thread * 1e3, 1), "compute_hamming_thread_cores": ncore,
+        "match_hamming_count_plus_prealloc_ms": round(t_match * 1e3, 1), "match_cores": 1,
+        "sample": "the whole workload, once",
+        "gpu_matrix_equal": bool(np.array_equal(dis, rdis)),
+        "gpu_matches_equal": bool(np.array_equal(idx, ridx) and np.array_equal(hams, rhams))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -472,6 +529,7 @@ def main():
                 del dL, dR, dO
                 torch.cuda.empty_cache()
                 out["secondary"].update(other_configs(sv, torch, local_rank))
+                out["secondary"]["hamming_library"] = hamming_library_leg(sv, local_rank)
         print(json.dumps(out), flush=True)
 
     if use_dist:

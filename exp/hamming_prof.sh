@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage: exp/hamming_prof.sh name   -- kernel stats of exp/hamming_time.py (SGMX_LIB passes through)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/$1 -- python3 exp/hamming_time.py > gpurun_out/r03/$1.log 2>&1 || { tail -n 20 gpurun_out/r03/$1.log; exit 1; }
+cat gpurun_out/r03/$1.log
+python3 - <<PY
+import csv, glob
+f = glob.glob('gpurun_out/r03/$1/*/*kernel_stats.csv')[0]
+for r in csv.DictReader(open(f)):
+    if 'ham' in r['Name']:
+        print("  %-60s calls %4s  avg %10.1f us" % (r['Name'].split('(')[0][-60:], r['Calls'], float(r['AverageNs']) / 1e3))
+PY

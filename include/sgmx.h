@@ -235,7 +235,8 @@ SGMX_API int sgmx_crossmatch_hamming_prealloc(sgmx_ctx *ctx, const uint8_t *dbs,
  *   sgmx_crossmatch_hamming         crossmatch_hamming          core/hamming.h:95-96, core/hamming.c:768-807
  *     *hmptr receives a malloc'ed array of at least max(bufsize, 1) records (the reference mallocs bufsize and grows
  *     it by realloc), *nptr the number of matches, records in the reference's loop order; release with
- *     sgmx_free (= free()).  On an error return *hmptr is still a valid malloc'ed (or NULL) pointer to release.
+ *     sgmx_free (= free()).  On an error return *hmptr is NULL (argument errors) or a valid malloc'ed pointer to
+ *     release.
  *   sgmx_compute_hamming_thread     compute_hamming_thread      core/hamming.h:108-109, core/hamming.c:849-860
  *     the same matrix as compute_hamming.
  *   sgmx_match_hamming_thres_nt     match_hamming_thres_nt      core/hamming.h:111-112, core/hamming.c:863-919
@@ -294,7 +295,8 @@ enum {
     SGMX_K_AGGREGATE = 2, /* all directions; one launch per direction per launch group */
     SGMX_K_WTA = 3,
     SGMX_K_MEDIAN = 4,
-    SGMX_K_COUNT = 5
+    SGMX_K_HAMLIB = 5, /* the distance and matching kernels of the core/hamming entry points */
+    SGMX_K_COUNT = 6
 };
 
 /* When enabled every kernel launch is bracketed by HIP events on the launch

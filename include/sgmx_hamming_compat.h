@@ -7,12 +7,20 @@
  * error aborts with its text on stderr, where the reference would have crashed or returned garbage.  Buffers that the
  * reference allocates with malloc are malloc'ed here too: release them with free().
  *
+ * Threads: the reference's functions are re-entrant; an sgmx context is not (sgmx.h: one context per host thread), so
+ * every call below holds one process-wide mutex while it uses the shared context -- calls from several threads are
+ * correct and run one after the other (the GPU would serialise them anyway).
+ * hamming() (core/hamming.h:62), the distance of ONE pair of signatures, is a popcount loop on the host: a GPU round
+ * trip for one popcount would make code that calls it in a loop orders of magnitude slower than the reference.  Every
+ * function that works on sets of signatures runs on the GPU.
+ *
  * Define SGMX_HAMMING_COMPAT_EXPORT before including to get external (non-static) definitions, e.g. to build a
  * drop-in libhamming.so from a one-line .c file.
  */
 #ifndef SGMX_HAMMING_COMPAT_H
 #define SGMX_HAMMING_COMPAT_H
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -60,20 +68,27 @@ static sgmx_ctx *sgmx_hc_ctx(void)
     return c;
 }
 
-static void sgmx_hc_check(int rc)
+/* The shared context is used by one thread at a time: sgmx_hc_check(CALL) runs CALL under the mutex. */
+static pthread_mutex_t sgmx_hc_mutex = PTHREAD_MUTEX_INITIALIZER;
+
+static void sgmx_hc_done(int rc)
 {
     if (rc != SGMX_OK) {
         fprintf(stderr, "sgmx hamming: %s\n", sgmx_last_error(sgmx_hc_ctx()));
         abort();
     }
+    pthread_mutex_unlock(&sgmx_hc_mutex);
 }
+#define sgmx_hc_check(call) (pthread_mutex_lock(&sgmx_hc_mutex), sgmx_hc_done(call))
 
-/* core/hamming.h:62 */
+/* core/hamming.h:62 -- one pair: on the host (see the head of this file) */
 SGMX_HC uint16 hamming(const uint8 *bs1, const uint8 *bs2, int ncodes)
 {
-    uint16 d = 0;
-    sgmx_hc_check(sgmx_hamming_matrix_u16(sgmx_hc_ctx(), &d, bs1, bs2, 1, 1, ncodes));
-    return d;
+    unsigned d = 0;
+    int k;
+    for (k = 0; k < ncodes; k++)
+        d += (unsigned)__builtin_popcount((unsigned)(bs1[k] ^ bs2[k]));
+    return (uint16)d;
 }
 
 /* core/hamming.h:67-68 */

@@ -10,8 +10,8 @@ LIB_PATH = os.environ.get("SGMX_LIB") or os.path.join(_HERE, "libsgmx.so")  # SG
 SGMX_OK = 0
 FLAG_MATERIALIZE = 1  # SGMX_FLAG_MATERIALIZE
 ERR_NAMES = {1: "INVALID_ARG", 2: "RANGE", 3: "NO_DEVICE", 4: "HIP", 5: "OOM", 6: "STATE"}
-K_CENSUS, K_HAMMING, K_AGGREGATE, K_WTA, K_MEDIAN, K_COUNT = range(6)
-KERNEL_CLASS_NAMES = ["census", "hamming_volume", "aggregate", "wta", "median"]
+K_CENSUS, K_HAMMING, K_AGGREGATE, K_WTA, K_MEDIAN, K_HAMLIB, K_COUNT = range(7)
+KERNEL_CLASS_NAMES = ["census", "hamming_volume", "aggregate", "wta", "median", "hamming_library"]
 
 
 class SgmxParams(C.Structure):

@@ -83,6 +83,8 @@ hipError_t noalloc_scratch_for_device(int device, unsigned char **out)
 }
 } // namespace
 
+enum { HAM_A = 0, HAM_B, HAM_CNT, HAM_IDX, HAM_H, HAM_DIS, HAM_REC, HAM_SLOTS };
+
 struct sgmx_ctx {
     sgmx_params prm;
     int R = 1;  // packed uint16 pairs per lane (census) / float pairs per lane (float path)
@@ -127,6 +129,11 @@ struct sgmx_ctx {
     float *d_C2 = nullptr, *d_sub = nullptr;
     int *d_ld = nullptr, *d_rd = nullptr, *d_label = nullptr, *d_size = nullptr;
     uint8_t *d_states = nullptr;
+
+    // Grow-only device buffers of the Hamming-library entry points (signatures, counts, matches, the distance
+    // matrix): kept from call to call instead of a hipMalloc / hipFree per buffer and call; freed with the context.
+    void *ham_buf[HAM_SLOTS] = {nullptr};
+    size_t ham_cap[HAM_SLOTS] = {0};
 
     hipStream_t own_stream = nullptr;
     bool profiling = false;
@@ -904,6 +911,9 @@ void sgmx_destroy(sgmx_ctx *ctx)
         (void)hipEventDestroy(r.b);
     }
     free_scratch(ctx);
+    for (void *p : ctx->ham_buf)
+        if (p)
+            (void)hipFree(p);
     for (int i = 0; i < 2; i++)
         for (hipEvent_t ev : {ctx->ev_in[i], ctx->ev_done[i], ctx->ev_out[i]})
             if (ev)
@@ -1547,34 +1557,81 @@ int sgmx_hamming_volume_u8(sgmx_ctx *c, const uint32_t *cl, const uint32_t *cr, 
     return SGMX_OK;
 }
 
+// One of the context's grow-only Hamming buffers, at least `bytes` large (the previous call's stream work has been
+// waited for: every Hamming entry point synchronises before it returns).
+static hipError_t ham_buffer(sgmx_ctx *c, int slot, size_t bytes, void **out)
+{
+    if (c->ham_cap[slot] < bytes) {
+        if (c->ham_buf[slot])
+            (void)hipFree(c->ham_buf[slot]);
+        c->ham_buf[slot] = nullptr;
+        c->ham_cap[slot] = 0;
+        const size_t want = bytes + bytes / 4 + 256; // some room, so that slowly growing inputs do not reallocate every call
+        hipError_t e = hipMalloc(&c->ham_buf[slot], want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipMalloc(&c->ham_buf[slot], bytes);
+            if (e != hipSuccess)
+                return e;
+            c->ham_cap[slot] = bytes;
+        } else {
+            c->ham_cap[slot] = want;
+        }
+    }
+    *out = c->ham_buf[slot];
+    return hipSuccess;
+}
+
+// signatures of 4, 8, 16, 32 bytes (the reference's fast paths are 4 / 8 / 16, core/hamming.c:183-213) run the
+// register-tiled kernels
+#ifndef SGMX_HAM_NAIVE // (1: A/B builds only -- every signature length through the generic one-thread-per-distance kernels)
+#define SGMX_HAM_NAIVE 0
+#endif
+static int ham_words(int ncodes)
+{
+    if (SGMX_HAM_NAIVE)
+        return 0;
+    return ncodes == 4 ? 1 : ncodes == 8 ? 2 : ncodes == 16 ? 4 : ncodes == 32 ? 8 : 0;
+}
+
 int sgmx_hamming_matrix_u16(sgmx_ctx *c, uint16_t *dis, const uint8_t *a, const uint8_t *b, int na, int nb, int ncodes)
 {
     if (!c || !dis || !a || !b || na < 1 || nb < 1 || ncodes < 1)
         return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
     HIPCHK(c, hipSetDevice(c->prm.device));
-    uint8_t *d_a = nullptr, *d_b = nullptr;
-    uint16_t *d_d = nullptr;
-    hipError_t e = hipMalloc((void **)&d_a, (size_t)na * ncodes + 4);
+    void *d_a = nullptr, *d_b = nullptr, *d_d = nullptr;
+    hipError_t e = ham_buffer(c, HAM_A, (size_t)na * ncodes + 4, &d_a);
     if (e == hipSuccess)
-        e = hipMalloc((void **)&d_b, (size_t)nb * ncodes + 4);
+        e = ham_buffer(c, HAM_B, (size_t)nb * ncodes + 4, &d_b);
     if (e == hipSuccess)
-        e = hipMalloc((void **)&d_d, (size_t)na * nb * 2);
+        e = ham_buffer(c, HAM_DIS, (size_t)na * nb * 2, &d_d);
     hipStream_t st = c->own_stream;
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_a, a, (size_t)na * ncodes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_b, b, (size_t)nb * ncodes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(hamming_matrix_kernel, dim3((na + 255) / 256, nb), dim3(256), 0, st, d_d, d_a, d_b, na, nb,
-                           ncodes);
+        {
+            ProfScope ps(c, SGMX_K_HAMLIB, st);
+            const dim3 tg((na + 256 * HAM_II - 1) / (256 * HAM_II), (nb + HAM_JT - 1) / HAM_JT);
+            const u32 *wa = static_cast<const u32 *>(d_a), *wb = static_cast<const u32 *>(d_b);
+            uint16_t *dd = static_cast<uint16_t *>(d_d);
+            switch (ham_words(ncodes)) {
+            case 1: hipLaunchKernelGGL(hamming_matrix_tiled_kernel<1>, tg, dim3(256), 0, st, dd, wa, wb, na, nb); break;
+            case 2: hipLaunchKernelGGL(hamming_matrix_tiled_kernel<2>, tg, dim3(256), 0, st, dd, wa, wb, na, nb); break;
+            case 4: hipLaunchKernelGGL(hamming_matrix_tiled_kernel<4>, tg, dim3(256), 0, st, dd, wa, wb, na, nb); break;
+            case 8: hipLaunchKernelGGL(hamming_matrix_tiled_kernel<8>, tg, dim3(256), 0, st, dd, wa, wb, na, nb); break;
+            default:
+                hipLaunchKernelGGL(hamming_matrix_kernel, dim3((na + 255) / 256, nb), dim3(256), 0, st, dd,
+                                   static_cast<const uint8_t *>(d_a), static_cast<const uint8_t *>(d_b), na, nb, ncodes);
+            }
+        }
         e = hipMemcpyAsync(dis, d_d, (size_t)na * nb * 2, hipMemcpyDeviceToHost, st);
     }
-    hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(d_a);
-    (void)hipFree(d_b);
-    (void)hipFree(d_d);
+    const hipError_t e2 = hipStreamSynchronize(st);
     if (e != hipSuccess || e2 != hipSuccess)
-        return fail(c, SGMX_ERR_HIP, std::string("hamming matrix: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+        return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP,
+                    std::string("hamming matrix: ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return SGMX_OK;
 }
 
@@ -1583,103 +1640,129 @@ int sgmx_hamming_matrix_u16(sgmx_ctx *c, uint16_t *dis, const uint8_t *a, const 
 // records != nullptr: the allocating forms (match_hamming_thres, crossmatch_hamming; core/hamming.c:533-577, 768-807):
 // once the count is known a buffer of max(bufsize, count, 1) hammatch_t records is malloc'ed into *records (the
 // reference mallocs bufsize and grows by realloc; the caller frees it either way) and filled in loop order.
+// Exclusive prefix sum of the n counts at d_cnt in place, their total to d_cnt[n]; the block sums of the three-launch
+// form live behind it (the HAM_CNT buffer holds ham_scan_room(n) counts).
+static size_t ham_scan_room(size_t n) { return n + 2 + (n + 1023) / 1024 + 1; }
+static void ham_scan(unsigned long long *d_cnt, long n, hipStream_t st)
+{
+    if (n <= 4096) {
+        hipLaunchKernelGGL(ham_scan_kernel, dim3(1), dim3(1024), 0, st, d_cnt, (int)n, d_cnt + n);
+        return;
+    }
+    const int nblk = (int)((n + 1023) / 1024);
+    unsigned long long *bsum = d_cnt + n + 1;
+    hipLaunchKernelGGL(ham_scan_blocks_kernel, dim3(nblk), dim3(1024), 0, st, d_cnt, (int)n, bsum);
+    hipLaunchKernelGGL(ham_scan_kernel, dim3(1), dim3(1024), 0, st, bsum, nblk, d_cnt + n);
+    hipLaunchKernelGGL(ham_scan_add_kernel, dim3(nblk), dim3(1024), 0, st, d_cnt, (int)n, bsum);
+}
+
 static int ham_match(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, long n1, long n2, int ht, int ncodes, bool cross,
                      int *idx, uint16_t *hams, size_t capacity, size_t *nptr, sgmx_hammatch **records = nullptr,
                      size_t bufsize = 0)
 {
-    if (records) {
-        if (!c || !nptr)
-            return fail(c, SGMX_ERR_INVALID_ARG, "null pointer");
-        *records = static_cast<sgmx_hammatch *>(std::malloc((bufsize ? bufsize : 1) * sizeof(sgmx_hammatch)));
-        if (!*records)
-            return fail(c, SGMX_ERR_OOM, "host allocation failed");
-    }
+    if (records)
+        *records = nullptr; // argument errors leave nothing to release
     if (!c || !nptr || n1 < 0 || n2 < 0 || ncodes < 1 || n1 > 0x7fffffffL || n2 > 0x7fffffffL || (n1 > 0 && !bs1) ||
         (!cross && n2 > 0 && !bs2) || (idx && !hams))
         return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size");
     *nptr = 0;
+    if (records) {
+        *records = static_cast<sgmx_hammatch *>(std::malloc((bufsize ? bufsize : 1) * sizeof(sgmx_hammatch)));
+        if (!*records)
+            return fail(c, SGMX_ERR_OOM, "host allocation failed");
+    }
     if (n1 == 0 || n2 == 0)
         return SGMX_OK;
     HIPCHK(c, hipSetDevice(c->prm.device));
     hipStream_t st = c->own_stream;
-    uint8_t *d_a = nullptr, *d_b = nullptr;
-    unsigned long long *d_cnt = nullptr;
-    int *d_idx = nullptr;
-    uint16_t *d_h = nullptr;
+    void *d_a = nullptr, *d_b = nullptr, *d_cntv = nullptr, *d_idx = nullptr, *d_h = nullptr, *d_rec = nullptr;
     unsigned long long total = 0;
-    auto cleanup = [&]() {
-        (void)hipFree(d_a);
-        if (d_b != d_a)
-            (void)hipFree(d_b);
-        (void)hipFree(d_cnt);
-        (void)hipFree(d_idx);
-        (void)hipFree(d_h);
-    };
-    hipError_t e = hipMalloc((void **)&d_a, (size_t)n1 * ncodes + 4);
+    hipError_t e = ham_buffer(c, HAM_A, (size_t)n1 * ncodes + 4, &d_a);
     if (e == hipSuccess) {
         if (cross)
             d_b = d_a;
         else
-            e = hipMalloc((void **)&d_b, (size_t)n2 * ncodes + 4);
+            e = ham_buffer(c, HAM_B, (size_t)n2 * ncodes + 4, &d_b);
     }
     if (e == hipSuccess)
-        e = hipMalloc((void **)&d_cnt, ((size_t)n1 + 1) * sizeof(unsigned long long));
+        e = ham_buffer(c, HAM_CNT, ham_scan_room((size_t)n1) * sizeof(unsigned long long), &d_cntv);
+    unsigned long long *d_cnt = static_cast<unsigned long long *>(d_cntv);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_a, bs1, (size_t)n1 * ncodes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && !cross)
         e = hipMemcpyAsync(d_b, bs2, (size_t)n2 * ncodes, hipMemcpyHostToDevice, st);
-    const dim3 grid((unsigned)((n1 + 3) / 4));
+    const int nw = ham_words(ncodes);
+    const dim3 grid((unsigned)((n1 + 3) / 4)), tgrid((unsigned)((n1 + 4 * HAM_QW - 1) / (4 * HAM_QW)));
+    const uint8_t *ba = static_cast<const uint8_t *>(d_a), *bb = static_cast<const uint8_t *>(d_b);
+    const u32 *wa = static_cast<const u32 *>(d_a), *wb = static_cast<const u32 *>(d_b);
+    // count (emit == false) or emit pass
+    auto pass = [&](bool emit) {
+        ProfScope ps(c, SGMX_K_HAMLIB, st);
+        int *di = static_cast<int *>(d_idx);
+        uint16_t *dh = static_cast<uint16_t *>(d_h);
+#define SGMX_HAM_PASS(NW)                                                                                              \
+    do {                                                                                                               \
+        if (emit)                                                                                                      \
+            hipLaunchKernelGGL((ham_match_tiled_kernel<NW, true>), tgrid, dim3(256), 0, st, wa, wb, (int)n1, (int)n2, ht, cross ? 1 : 0, \
+                               d_cnt, total, di, dh);                                                                  \
+        else                                                                                                           \
+            hipLaunchKernelGGL((ham_match_tiled_kernel<NW, false>), tgrid, dim3(256), 0, st, wa, wb, (int)n1, (int)n2, ht, cross ? 1 : 0, \
+                               d_cnt, 0ull, (int *)nullptr, (uint16_t *)nullptr);                                      \
+    } while (0)
+        switch (nw) {
+        case 1: SGMX_HAM_PASS(1); break;
+        case 2: SGMX_HAM_PASS(2); break;
+        case 4: SGMX_HAM_PASS(4); break;
+        case 8: SGMX_HAM_PASS(8); break;
+        default:
+            if (emit)
+                hipLaunchKernelGGL(ham_emit_kernel, grid, dim3(256), 0, st, ba, bb, (int)n1, (int)n2, ncodes, ht, cross ? 1 : 0, d_cnt,
+                                   total, di, dh);
+            else
+                hipLaunchKernelGGL(ham_count_kernel, grid, dim3(256), 0, st, ba, bb, (int)n1, (int)n2, ncodes, ht, cross ? 1 : 0, d_cnt);
+        }
+#undef SGMX_HAM_PASS
+    };
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(ham_count_kernel, grid, dim3(256), 0, st, d_a, d_b, (int)n1, (int)n2, ncodes, ht, cross ? 1 : 0, d_cnt);
-        hipLaunchKernelGGL(ham_scan_kernel, dim3(1), dim3(1024), 0, st, d_cnt, (int)n1, d_cnt + n1);
+        pass(false);
+        ham_scan(d_cnt, n1, st);
         e = hipMemcpyAsync(&total, d_cnt + n1, sizeof(total), hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        cleanup();
+    if (e != hipSuccess)
         return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP, std::string("hamming match: ") + hipGetErrorString(e));
-    }
     *nptr = (size_t)total;
-    if ((!idx && !records) || total == 0) {
-        cleanup();
+    if ((!idx && !records) || total == 0)
         return SGMX_OK;
-    }
     if (records && (size_t)total > (bufsize ? bufsize : 1)) {
         void *grown = std::realloc(*records, (size_t)total * sizeof(sgmx_hammatch));
-        if (!grown) {
-            cleanup();
+        if (!grown)
             return fail(c, SGMX_ERR_OOM, "host allocation failed");
-        }
         *records = static_cast<sgmx_hammatch *>(grown);
     }
-    if (!records && (size_t)total > capacity) {
-        cleanup();
+    if (!records && (size_t)total > capacity)
         return fail(c, SGMX_ERR_INVALID_ARG, "hamming match: more matches than the caller's capacity (count first)");
-    }
-    e = hipMalloc((void **)&d_idx, (size_t)total * 2 * sizeof(int));
+    e = ham_buffer(c, HAM_IDX, (size_t)total * 2 * sizeof(int), &d_idx);
     if (e == hipSuccess)
-        e = hipMalloc((void **)&d_h, (size_t)total * sizeof(uint16_t));
+        e = ham_buffer(c, HAM_H, (size_t)total * sizeof(uint16_t), &d_h);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(ham_emit_kernel, grid, dim3(256), 0, st, d_a, d_b, (int)n1, (int)n2, ncodes, ht, cross ? 1 : 0, d_cnt,
-                           total, d_idx, d_h);
+        pass(true);
         if (!records)
             e = hipMemcpyAsync(idx, d_idx, (size_t)total * 2 * sizeof(int), hipMemcpyDeviceToHost, st);
     }
-    int *d_rec = nullptr;
     if (e == hipSuccess && !records)
         e = hipMemcpyAsync(hams, d_h, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && records) {
         static_assert(sizeof(sgmx_hammatch) == 12, "hammatch_t is two ints and a uint16 (core/hamming.h:52-56)");
-        e = hipMalloc((void **)&d_rec, (size_t)total * sizeof(sgmx_hammatch));
+        e = ham_buffer(c, HAM_REC, (size_t)total * sizeof(sgmx_hammatch), &d_rec);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(ham_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_idx, d_h, total, d_rec);
+            hipLaunchKernelGGL(ham_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, static_cast<const int *>(d_idx),
+                               static_cast<const uint16_t *>(d_h), total, static_cast<int *>(d_rec));
             e = hipMemcpyAsync(*records, d_rec, (size_t)total * sizeof(sgmx_hammatch), hipMemcpyDeviceToHost, st);
         }
     }
     const hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(d_rec);
-    cleanup();
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP,
                     std::string("hamming match: ") + hipGetErrorString(e != hipSuccess ? e : e2));
@@ -1757,18 +1840,12 @@ int sgmx_match_hamming_thres_nt(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *
     unsigned long long *d_cnt = nullptr, total = 0;
     int *d_idx = nullptr;
     uint16_t *d_h = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_a);
-        (void)hipFree(d_b);
-        (void)hipFree(d_cnt);
-        (void)hipFree(d_idx);
-        (void)hipFree(d_h);
-    };
-    hipError_t e = hipMalloc((void **)&d_a, (size_t)n1 * ncodes + 4);
+    auto cleanup = [&]() {}; // (the buffers are the context's grow-only ones)
+    hipError_t e = ham_buffer(c, HAM_A, (size_t)n1 * ncodes + 4, (void **)&d_a);
     if (e == hipSuccess)
-        e = hipMalloc((void **)&d_b, (size_t)n2 * ncodes + 4);
+        e = ham_buffer(c, HAM_B, (size_t)n2 * ncodes + 4, (void **)&d_b);
     if (e == hipSuccess)
-        e = hipMalloc((void **)&d_cnt, ((size_t)nitems + 1) * sizeof(unsigned long long));
+        e = ham_buffer(c, HAM_CNT, ham_scan_room((size_t)nitems) * sizeof(unsigned long long), (void **)&d_cnt);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_a, bs1, (size_t)n1 * ncodes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
@@ -1776,7 +1853,7 @@ int sgmx_match_hamming_thres_nt(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *
     const dim3 grid((unsigned)((nitems + 3) / 4));
     if (e == hipSuccess) {
         hipLaunchKernelGGL(ham_count_blocked_kernel, grid, dim3(256), 0, st, d_a, d_b, g, nitems, ncodes, ht, d_cnt);
-        hipLaunchKernelGGL(ham_scan_kernel, dim3(1), dim3(1024), 0, st, d_cnt, (int)nitems, d_cnt + nitems);
+        ham_scan(d_cnt, nitems, st);
         e = hipMemcpyAsync(&total, d_cnt + nitems, sizeof(total), hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess)
@@ -1795,9 +1872,9 @@ int sgmx_match_hamming_thres_nt(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *
         }
     }
     if (e == hipSuccess && total > 0) {
-        e = hipMalloc((void **)&d_idx, (size_t)total * 2 * sizeof(int));
+        e = ham_buffer(c, HAM_IDX, (size_t)total * 2 * sizeof(int), (void **)&d_idx);
         if (e == hipSuccess)
-            e = hipMalloc((void **)&d_h, (size_t)total * sizeof(uint16_t));
+            e = ham_buffer(c, HAM_H, (size_t)total * sizeof(uint16_t), (void **)&d_h);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(ham_emit_blocked_kernel, grid, dim3(256), 0, st, d_a, d_b, g, nitems, ncodes, ht, d_cnt, d_idx, d_h);
             e = hipMemcpyAsync(*keys, d_idx, (size_t)total * 2 * sizeof(int), hipMemcpyDeviceToHost, st);

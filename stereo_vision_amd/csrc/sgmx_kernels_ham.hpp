@@ -75,6 +75,44 @@ __global__ __launch_bounds__(1024) void ham_scan_kernel(unsigned long long *__re
     }
 }
 
+// The same prefix sum for many counts, in three launches: every workgroup scans its own 1024 counts in place
+// (coalesced loads, wave scans by DPP-free shuffles through LDS) and leaves their sum in bsum; ham_scan_kernel scans
+// the sums; ham_scan_add_kernel adds every workgroup's offset.  (One workgroup walking 100 000 counts in per-thread
+// chunks took 140 us, as long as the counting kernel itself.)
+__global__ __launch_bounds__(1024) void ham_scan_blocks_kernel(unsigned long long *__restrict__ v, int n,
+                                                               unsigned long long *__restrict__ bsum)
+{
+    __shared__ unsigned long long wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int k = blockIdx.x * 1024 + t;
+    const unsigned long long x = k < n ? v[k] : 0ull;
+    unsigned long long inc = x; // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = __shfl_up(inc, d, 64);
+        if (lane >= d)
+            inc += y;
+    }
+    if (lane == 63)
+        wsum[wv] = inc;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int w2 = 0; w2 < wv; w2++)
+        base += wsum[w2];
+    if (k < n)
+        v[k] = base + inc - x;
+    if (t == 1023)
+        bsum[blockIdx.x] = base + inc;
+}
+
+__global__ __launch_bounds__(1024) void ham_scan_add_kernel(unsigned long long *__restrict__ v, int n,
+                                                            const unsigned long long *__restrict__ boff)
+{
+    const int k = blockIdx.x * 1024 + threadIdx.x;
+    if (k < n)
+        v[k] += boff[blockIdx.x];
+}
+
 // Matches of query i go to positions offs[i] ... in loop order: idx[2p] = i, idx[2p+1] = j, hams[p] = distance.
 // Positions >= capacity are dropped (the host reports the overflow).
 __global__ __launch_bounds__(256) void ham_emit_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int n1,
@@ -107,6 +145,134 @@ __global__ __launch_bounds__(256) void ham_emit_kernel(const uint8_t *__restrict
             }
         }
         pos += (unsigned long long)__builtin_popcountll(m);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// compute_hamming (core/hamming.c:167-236: dis[j * na + i] = popcount(a_i xor b_j), fast paths for 4 / 8 / 16-byte
+// codes) for signatures of NW dwords.  The matrix is write-bound (2 bytes out per distance, 8 NW VALU lane
+// operations): a thread keeps HAM_II = 8 neighbouring signatures a_i in registers, walks HAM_JT rows b_j (one
+// address per wave: scalar loads) and stores the 8 distances of a row as one 16-byte piece -- a wave writes 1 KB
+// of a matrix row per store.
+// ---------------------------------------------------------------------------
+constexpr int HAM_II = 8, HAM_JT = 32;
+
+// 8 uint16 (packed in 4 dwords) to a 2-byte aligned address: one 16-byte store when it is 4-byte aligned, else a
+// leading and a trailing halfword around three dwords
+__device__ __forceinline__ void ham_store8(uint16_t *p, const u32 (&v)[4])
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 2) == 0) {
+        __builtin_memcpy(__builtin_assume_aligned(p, 4), v, 16);
+    } else {
+        p[0] = (uint16_t)v[0];
+        u32 m[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            m[k] = __builtin_amdgcn_alignbit(v[k + 1], v[k], 16);
+        __builtin_memcpy(__builtin_assume_aligned(p + 1, 4), m, 12);
+        p[7] = (uint16_t)(v[3] >> 16);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void hamming_matrix_tiled_kernel(uint16_t *__restrict__ dis, const u32 *__restrict__ a,
+                                                                   const u32 *__restrict__ b, int na, int nb)
+{
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * HAM_II;
+    if (i0 >= na)
+        return;
+    u32 wa[HAM_II][NW];
+#pragma unroll
+    for (int k = 0; k < HAM_II; k++) {
+        const int i = i0 + k < na ? i0 + k : na - 1;
+        __builtin_memcpy(wa[k], a + (size_t)i * NW, 4 * NW);
+    }
+    const int j0 = blockIdx.y * HAM_JT, j1 = j0 + HAM_JT < nb ? j0 + HAM_JT : nb;
+    const bool full = i0 + HAM_II <= na;
+    for (int j = j0; j < j1; j++) {
+        u32 wb[NW];
+        __builtin_memcpy(wb, b + (size_t)j * NW, 4 * NW); // one address per workgroup: scalar loads
+        u32 d[HAM_II];
+#pragma unroll
+        for (int k = 0; k < HAM_II; k++) {
+            u32 s = 0;
+#pragma unroll
+            for (int n = 0; n < NW; n++)
+                s += (u32)__builtin_popcount(wa[k][n] ^ wb[n]);
+            d[k] = s;
+        }
+        uint16_t *row = dis + (size_t)j * na + i0;
+        if (full) {
+            u32 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                v[k] = d[2 * k] | (d[2 * k + 1] << 16);
+            ham_store8(row, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < HAM_II; k++)
+                if (i0 + k < na)
+                    row[k] = (uint16_t)d[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The matchers for signatures of NW dwords: a wave owns HAM_QW = 8 consecutive queries, whose words sit in
+// registers (one address per wave), and walks the base signatures 64 at a time -- every lane loads its b_j once
+// for the 8 queries (the one-query-per-wave kernels above read the whole base set once per query).  EMIT = false
+// counts, EMIT = true places the matches of query i from offs[i] on by ballot rank: the reference's loop order
+// (query outer, base inner; cross: j > i only).
+// ---------------------------------------------------------------------------
+constexpr int HAM_QW = 8;
+
+template <int NW, bool EMIT>
+__global__ __launch_bounds__(256) void ham_match_tiled_kernel(const u32 *__restrict__ a, const u32 *__restrict__ b, int n1, int n2,
+                                                              int ht, int cross, unsigned long long *__restrict__ counts,
+                                                              unsigned long long capacity, int *__restrict__ idx,
+                                                              uint16_t *__restrict__ hams)
+{
+    const int lane = threadIdx.x & 63;
+    const int q0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * HAM_QW;
+    if (q0 >= n1)
+        return;
+    u32 wa[HAM_QW][NW];
+    unsigned long long pos[HAM_QW];
+#pragma unroll
+    for (int k = 0; k < HAM_QW; k++) {
+        const int i = q0 + k < n1 ? q0 + k : n1 - 1;
+        __builtin_memcpy(wa[k], a + (size_t)i * NW, 4 * NW);
+        pos[k] = EMIT ? counts[i] : 0ull; // (EMIT: counts holds the exclusive prefix sums)
+    }
+    for (int jb = cross ? q0 + 1 : 0; jb < n2; jb += 64) {
+        const int j = jb + lane;
+        u32 wb[NW] = {};
+        if (j < n2)
+            __builtin_memcpy(wb, b + (size_t)j * NW, 4 * NW);
+#pragma unroll
+        for (int k = 0; k < HAM_QW; k++) {
+            u32 h = 0;
+#pragma unroll
+            for (int n = 0; n < NW; n++)
+                h += (u32)__builtin_popcount(wa[k][n] ^ wb[n]);
+            const bool hit = j < n2 && (int)h <= ht && q0 + k < n1 && (!cross || j > q0 + k);
+            const unsigned long long m = __ballot(hit);
+            if (EMIT && hit) {
+                const unsigned long long p = pos[k] + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (p < capacity) {
+                    idx[2 * p] = q0 + k;
+                    idx[2 * p + 1] = j;
+                    hams[p] = (uint16_t)h;
+                }
+            }
+            pos[k] += (unsigned long long)__builtin_popcountll(m);
+        }
+    }
+    if (!EMIT && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < HAM_QW; k++)
+            if (q0 + k < n1)
+                counts[q0 + k] = pos[k];
     }
 }
 

@@ -606,3 +606,107 @@ def test_hamming_compat_library_is_a_drop_in_for_core_hamming(oracle):
     assert mine[0] == ref[0] and len(mine[3]) > 0 and len(mine[5]) > 0
     for x, y in zip(mine[1:], ref[1:]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (7, 3), (8, 33), (9, 32), (2047, 31), (2048, 5), (2049, 64), (4100, 65), (6151, 40)],
+                         ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("ncodes", [4, 8, 16, 32, 12])
+def test_hamming_matrix_tile_boundaries(oracle, shape, ncodes):
+    """compute_hamming (core/hamming.c:167-236) through the register-tiled kernel (8 signatures a_i per thread, 2048
+    per workgroup, 32 rows b_j per workgroup, 16-byte stores that are only 2-byte aligned when na is odd): set sizes
+    around every tile edge, against the restatement and the reference's own core/hamming.c.  ncodes = 12 runs the
+    generic kernel."""
+    na, nb = shape
+    rng = np.random.default_rng(na * 131 + nb + ncodes)
+    a = rng.integers(0, 256, size=(na, ncodes)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(nb, ncodes)).astype(np.uint8)
+    e = make()
+    got = e.hamming_matrix(a, b)
+    assert np.array_equal(got, oracle.hamming_matrix(a, b))
+    ref = oracle.ref_hamming_matrix(a, b)
+    if ref is not None:
+        assert np.array_equal(got, ref)
+    # the context's buffers are kept from call to call: a smaller and a larger call on the same context
+    a2 = rng.integers(0, 256, size=(max(1, na // 3), ncodes)).astype(np.uint8)
+    assert np.array_equal(e.hamming_matrix(a2, b), oracle.hamming_matrix(a2, b))
+    a3 = rng.integers(0, 256, size=(na + 77, ncodes)).astype(np.uint8)
+    assert np.array_equal(e.hamming_matrix(a3, b), oracle.hamming_matrix(a3, b))
+    e.close()
+
+
+@pytest.mark.parametrize("ncodes,ht", [(4, 9), (8, 22), (16, 50), (32, 110)])
+@pytest.mark.parametrize("shape", [(1, 1), (7, 64), (8, 65), (9, 63), (33, 130), (257, 500), (4097, 40), (6200, 33)],
+                         ids=lambda s: "%dx%d" % s)
+def test_hamming_matchers_query_tiles(oracle, shape, ncodes, ht):
+    """The matchers' multi-query kernel (a wave owns 8 consecutive queries, 32 per workgroup): query counts around the
+    tile edges, base sets around the 64-lane chunks, more than 4096 queries (the prefix sum over the per-query counts
+    then runs as three launches), plain and cross matching, against the restatement and the reference's own
+    core/hamming.c (core/hamming.c:300-322, 385-407, 725-765, 810-839)."""
+    n1, n2 = shape
+    rng = np.random.default_rng(n1 * 7 + n2 + ncodes)
+    a = rng.integers(0, 256, size=(n1, ncodes)).astype(np.uint8)
+    b = rng.integers(0, 256, size=(n2, ncodes)).astype(np.uint8)
+    if n1 > 2 and n2 > 2:
+        b[n2 // 2] = a[n1 // 3]
+        a[n1 - 1] = a[1]
+    e = make()
+    for cross in (False, True):
+        want = oracle.match_hamming(a, b, ht, cross)
+        n = e.crossmatch_hamming_count(a, ht) if cross else e.match_hamming_count(a, b, ht)
+        idx, hams = e.crossmatch_hamming(a, ht) if cross else e.match_hamming_thres(a, b, ht)
+        assert n == len(want[1])
+        assert np.array_equal(idx, want[0]) and np.array_equal(hams, want[1])
+        ref = oracle.ref_match_hamming(a, b, ht, cross)
+        if ref is not None:
+            assert np.array_equal(idx, ref[0]) and np.array_equal(hams, ref[1])
+    e.close()
+
+
+def test_hamming_compat_library_from_several_threads(oracle):
+    """The reference's functions are re-entrant; the drop-in library serialises its calls on one shared context
+    (include/sgmx_hamming_compat.h).  Eight threads call compute_hamming and match_hamming_count on their own inputs
+    at the same time: every result equals the restatement's."""
+    import ctypes as C
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    L = C.CDLL(os.path.join(root, "stereo_vision_amd", "libhamming_sgmx.so"))
+    L.hamming.argtypes, L.hamming.restype = [u8p, u8p, C.c_int], C.c_uint16
+    L.compute_hamming.argtypes, L.compute_hamming.restype = [C.c_void_p, u8p, u8p, C.c_int, C.c_int, C.c_int], None
+    L.match_hamming_count.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    L.match_hamming_count.restype = None
+
+    def work(t):
+        rng = np.random.default_rng(900 + t)
+        ok = True
+        for rep in range(6):
+            na, nb, nc = int(rng.integers(1, 900)), int(rng.integers(1, 300)), int(rng.choice([4, 8, 16, 5]))
+            a = rng.integers(0, 256, size=(na, nc)).astype(np.uint8)
+            b = rng.integers(0, 256, size=(nb, nc)).astype(np.uint8)
+            dis = np.empty((nb, na), np.uint16)
+            L.compute_hamming(dis.ctypes.data, a, b, na, nb, nc)
+            want = oracle.hamming_matrix(a, b)
+            n = C.c_size_t(0)
+            L.match_hamming_count(a, b, na, nb, 3 * nc, nc, C.byref(n))
+            ok = ok and np.array_equal(dis, want) and n.value == int((want <= 3 * nc).sum())
+            ok = ok and int(L.hamming(a[:1].copy(), b[:1].copy(), nc)) == int(want[0, 0])
+        return ok
+
+    with ThreadPoolExecutor(8) as ex:  # ctypes calls release the GIL
+        assert all(ex.map(work, range(8)))
+
+
+def test_hamming_allocating_form_argument_errors_leave_null():
+    """sgmx.h: on an argument error *hmptr is NULL (nothing to release), whatever the caller's pointer held before."""
+    import ctypes as C
+    e = make()
+    hm = C.c_void_p(0xDEAD0)  # what an uninitialised hammatch_t* of the caller might hold
+    n = C.c_size_t(5)
+    a = np.zeros((4, 8), np.uint8)
+    rc = e.lib.sgmx_match_hamming_thres(e.h, a.ctypes.data, a.ctypes.data, 4, 4, 3, 0, 16, C.byref(hm), C.byref(n))  # ncodes = 0
+    assert rc == 1 and not hm.value
+    hm = C.c_void_p(0xDEAD0)
+    rc = e.lib.sgmx_crossmatch_hamming(e.h, None, 4, 3, 8, 16, C.byref(hm), C.byref(n))  # null signatures
+    assert rc == 1 and not hm.value
+    e.close()
