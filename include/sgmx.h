@@ -63,7 +63,7 @@ typedef struct sgmx_params {
     int num_paths;   /* 8 (default; order of stereo_sgm.cc:120-122) or 4 (its axis-aligned subset) */
     int device;      /* HIP device ordinal (default 0)                                           */
     int max_batch;   /* stereo pairs processed per launch group (default 1); sizes the scratch   */
-    int flags;       /* 0 or SGMX_FLAG_MATERIALIZE                                                */
+    int flags;       /* 0 or SGMX_FLAG_MATERIALIZE (SGMX_FLAG_NO_SMALL_GROUPS: accepted, ignored)  */
 } sgmx_params;
 
 /* flags: keep the data-cost volume C and the summed-cost volume S in HBM as the reference does
@@ -71,6 +71,10 @@ typedef struct sgmx_params {
  * census path recomputes C from the census images and stores one byte per voxel and direction
  * instead; the results are identical.  penalty2 > 255 always uses the materialised form. */
 #define SGMX_FLAG_MATERIALIZE 1
+/* Deprecated, accepted and ignored: round 1's contexts ran single pairs through the materialised form unless this
+ * flag was set; the volume-free form now serves every group size.  Kept so that callers built against that header
+ * still create their contexts. */
+#define SGMX_FLAG_NO_SMALL_GROUPS 2
 
 typedef struct sgmx_ctx sgmx_ctx;
 
@@ -122,9 +126,14 @@ SGMX_API int sgmx_compute_census_u8_dev(sgmx_ctx *ctx, int n, const uint8_t *d_l
  * context's scratch, no event is created, and nothing is allocated or freed on this path (sgmx_create, which
  * looks the array's address up once per device, is not part of it).
  * Limits: the volume-free formulation only (penalty2 <= 255, no SGMX_FLAG_MATERIALIZE), WTA row tables within
- * 64 KiB (width up to ~3 900), and one pair's buffers must fit the array -- e.g. 384x288 at D=16, 4 or 8 paths
- * (3 / 6 MB), 640x480 at D=64, 8 paths (160 MB: too large -> SGMX_ERR_INVALID_ARG with the byte count; use
- * sgmx_compute_census_u8_dev).  n pairs run in launch groups of as many pairs as fit (at most max_batch).
+ * 64 KiB (width up to ~3 900), and one pair's buffers must fit the array.  One pair needs (h w Dp) bytes per
+ * direction (h, w = cropped size, Dp = disp_range rounded up to 32, 64, 128, 256, 384 or 512) plus about 10 bytes
+ * per pixel: 384x288 at D=16 takes 15.1 MB with 4 paths and 28.9 MB with 8 (4 resp. 2 pairs per launch group fit);
+ * 288x200 at D=64, 8 paths 29.4 MB; 640x480 at D=64, 8 paths 159 MB: too large -> SGMX_ERR_INVALID_ARG with the byte
+ * count (use sgmx_compute_census_u8_dev).  n pairs run in launch groups of as many pairs as fit (at most max_batch).
+ * Under stream capture (hipStreamBeginCapture on `stream`, any capture mode) the call records its memsets and
+ * kernels into the graph and nothing else: tests/test_zz_no_alloc.py captures two calls in global capture mode,
+ * where hipMalloc / hipFree / synchronous copies would fail the capture, and replays the graph.
  * All calls on one GPU share that GPU's array, whatever the context: calls that overlap in time on one GPU
  * race; the array keeps the previous call's bytes and the call clears what must start at zero. */
 SGMX_API int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *ctx, int n, const uint8_t *d_left, const uint8_t *d_right, int W,
@@ -273,6 +282,10 @@ SGMX_API void sgmx_free(void *ptr);
  * (get_disparity_image_uint16, stereo_sgm.h:275-317 / sgm.h:285-332).  Any
  * pointer may be NULL. */
 SGMX_API int sgmx_get_stages_census(sgmx_ctx *ctx, int index, uint8_t *C, uint16_t *S, uint16_t *raw_disp);
+/* Which pairs the taps can reach: the last launch group of the last compute call held `count` pairs, the first of
+ * them pair `first_pair` of that call -- tap index i is the call's pair first_pair + i.  (E.g. 40 KITTI-size pairs
+ * with max_batch 40 run as launches of 32 + 8: first_pair 32, count 8.) */
+SGMX_API int sgmx_last_launch_group(const sgmx_ctx *ctx, int *first_pair, int *count);
 SGMX_API int sgmx_get_stages_f32(sgmx_ctx *ctx, int index, float *S, uint16_t *raw_disp);
 
 /* Stages of volume `index` of the last SGMStereo launch group: summed costs of the left pass (sum_cost_,

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -336,7 +337,8 @@ class SGMStereo {
                                         "smaller than large penalty value");
         // the reference keeps them as float (sgm_stereo.h:63-64); sgmx_params holds ints, so fractional
         // penalties are refused instead of truncated
-        if (P1 != (double)(int)P1 || P2 != (double)(int)P2)
+        // (NaN fails every comparison above and is caught here; the range check comes before any cast)
+        if (!std::isfinite(P1) || !std::isfinite(P2) || P2 > 2147483647.0 || std::trunc(P1) != P1 || std::trunc(P2) != P2)
             throw std::invalid_argument("[SGMStereo::SetSmoothnessCostParameters] this engine takes whole-number penalties");
         P1_ = (int)P1;
         P2_ = (int)P2;

@@ -99,6 +99,7 @@ struct sgmx_ctx {
     int RP = 4, DpF = 128;     // fast path: packed pairs per lane, padded disparity count 32 * RP
     int wp = 0;                // row pitch of the padded right census image (fast path)
     int last_n = 0;            // pairs in the last launch group
+    int last_first = 0;        // index of that group's first pair within the call that ran it
     int num_cus = 256;
     unsigned char *noalloc_scratch = nullptr; // this device's copy of sgmx_noalloc_scratch
     // The scratch below is shared by every call on this context.  ev_scratch is recorded behind the last
@@ -640,7 +641,8 @@ int fast_launch_pairs(const sgmx_ctx *c, int w, int h, int wp)
     return (int)g < c->prm.max_batch ? (int)g : c->prm.max_batch;
 }
 
-int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint16_t *d_disp, hipStream_t st)
+// base: index of the group's first pair within the caller's call (for sgmx_last_launch_group)
+int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint16_t *d_disp, hipStream_t st, int base = 0)
 {
     const int W = c->W, H = c->H, w = c->w, h = c->h;
     if (c->fast) {
@@ -654,6 +656,7 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
             if (!rc)
                 rc = run_fast(c, ctx_view(c), k, d_disp + i * nfull, st, true);
             c->last_n = k;
+            c->last_first = base + i;
         }
         if (!rc)
             rc = scratch_release(c, st);
@@ -674,6 +677,7 @@ int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint1
     if (!rc)
         rc = run_wta_median(c, n, false, d_disp, st);
     c->last_n = n;
+    c->last_first = base;
     if (!rc)
         rc = scratch_release(c, st);
     return rc;
@@ -734,7 +738,7 @@ template <int R> void launch_ns_wta(dim3 grid, hipStream_t st, const float *S, i
 // recon::SGMStereo::ComputeSGM (new_sgm/sgm_stereo.cc:58-101) on n <= max_batch left data-cost volumes of
 // pitch Dp, device resident.  The right-image pass runs first so that d_S holds the left sums afterwards
 // (for the tap); the two passes are independent.
-int ns_group(sgmx_ctx *c, int n, const float *left, int thr, uint16_t *d_disp, hipStream_t st)
+int ns_group(sgmx_ctx *c, int n, const float *left, int thr, uint16_t *d_disp, hipStream_t st, int base = 0)
 {
     const int w = c->w, h = c->h, D = c->prm.disp_range;
     const size_t npix = (size_t)w * h;
@@ -777,6 +781,7 @@ int ns_group(sgmx_ctx *c, int n, const float *left, int thr, uint16_t *d_disp, h
     }
     HIPCHK(c, hipGetLastError());
     c->last_n = n;
+    c->last_first = base;
     return scratch_release(c, st);
 }
 
@@ -859,7 +864,7 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "window_sz must be odd and in [1, 31]");
     if (p.num_paths != 4 && p.num_paths != 8)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "num_paths must be 4 or 8");
-    if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 || (p.flags & ~SGMX_FLAG_MATERIALIZE) != 0)
+    if (p.penalty1 < 0 || p.penalty2 < 0 || p.max_batch < 1 || p.max_batch > 4096 || (p.flags & ~(SGMX_FLAG_MATERIALIZE | SGMX_FLAG_NO_SMALL_GROUPS)) != 0)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "negative penalty, bad max_batch or unknown flags");
     if (p.device < 0 || p.device >= MAX_DEVICES)
         return fail(nullptr, SGMX_ERR_INVALID_ARG, "device ordinal out of range");
@@ -943,7 +948,7 @@ int sgmx_compute_census_u8_dev(sgmx_ctx *c, int n, const uint8_t *d_left, const 
     const size_t nfull = (size_t)W * H;
     for (int i = 0; i < n; i += c->prm.max_batch) {
         const int g = n - i < c->prm.max_batch ? n - i : c->prm.max_batch;
-        rc = census_group(c, g, d_left + i * nfull, d_right + i * nfull, d_disp + i * nfull, st);
+        rc = census_group(c, g, d_left + i * nfull, d_right + i * nfull, d_disp + i * nfull, st, i);
         if (rc)
             return rc;
     }
@@ -971,21 +976,38 @@ int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *c, int n, const uint8_t *d_left
     if (lds > 64 * 1024)
         return fail(c, SGMX_ERR_INVALID_ARG, "image too wide for the no-allocation entry point (WTA tables above 64 KiB "
                                              "would need a function attribute change)");
-    // layout of one launch group of g pairs in the scratch, every part 256-byte aligned
-    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // Layout of one launch group of g pairs in the scratch: ONE function gives the offsets the view below uses and the
+    // total the limit is checked against.  Pairs lie back to back inside a part at the sizes the kernels index with
+    // (direction k's byte volumes at E + k * g * b_E, as sum_args / run_fast address them); parts start 256-byte aligned.
     const size_t npix = (size_t)w * h, nfull = (size_t)W * H;
-    const size_t b_cl = up(npix * 4), b_cr = up((size_t)wp * h * 4), b_E = npix * c->DpF /* multiple of 32 */,
-                 b_ring = (size_t)(2 * w + 2 * h) * c->DpF * 2, b_raw = up(nfull * 2);
+    const size_t b_cl = npix * 4, b_cr = (size_t)wp * h * 4, b_E = npix * c->DpF, b_ring = (size_t)(2 * w + 2 * h) * c->DpF * 2,
+                 b_raw = nfull * 2;
     const int np = c->prm.num_paths;
-    auto need = [&](size_t g) { return g * (b_cl + b_cr + b_raw) + up(g * b_E) * np + 2 * up(g * b_ring); };
-    if (need(1) > SGMX_NOALLOC_SCRATCH_BYTES)
+    struct Layout {
+        size_t cl, cr, raw, E, BL, SB, total;
+    };
+    auto layout = [&](size_t g) {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        Layout L;
+        size_t off = 0;
+        L.cl = off, off = up(off + g * b_cl);
+        L.cr = off, off = up(off + g * b_cr);
+        L.raw = off, off = up(off + g * b_raw);
+        L.E = off, off = up(off + g * b_E * np);
+        L.BL = off, off = up(off + g * b_ring);
+        L.SB = off, off = up(off + g * b_ring);
+        L.total = off;
+        return L;
+    };
+    if (layout(1).total > SGMX_NOALLOC_SCRATCH_BYTES)
         return fail(c, SGMX_ERR_INVALID_ARG,
-                    "one pair needs " + std::to_string(need(1)) + " bytes of scratch; the no-allocation entry point has " +
+                    "one pair needs " + std::to_string(layout(1).total) + " bytes of scratch; the no-allocation entry point has " +
                         std::to_string(SGMX_NOALLOC_SCRATCH_BYTES) + " (use sgmx_compute_census_u8_dev)");
     int g = fast_launch_pairs(c, w, h, wp);
     g = n < g ? n : g;
-    while (need((size_t)g) > SGMX_NOALLOC_SCRATCH_BYTES)
+    while (layout((size_t)g).total > SGMX_NOALLOC_SCRATCH_BYTES)
         g--;
+    const Layout lay = layout((size_t)g);
     HIPCHK(c, hipSetDevice(c->prm.device));
     unsigned char *base = c->noalloc_scratch; // hipGetSymbolAddress result of this device (sgmx_create)
     if (!base)
@@ -995,15 +1017,12 @@ int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *c, int n, const uint8_t *d_left
     v.cap = g;
     v.bytes_E = b_E;
     v.bytes_BL = b_ring;
-    size_t off = 0;
-    v.cl = reinterpret_cast<u32 *>(base + off); off += (size_t)g * b_cl;
-    v.cr = reinterpret_cast<u32 *>(base + off); off += (size_t)g * b_cr;
-    v.raw = reinterpret_cast<uint16_t *>(base + off); off += (size_t)g * b_raw;
-    v.E = base + off; off += up((size_t)g * b_E) * np;
-    v.BL = reinterpret_cast<uint16_t *>(base + off); off += up((size_t)g * b_ring);
-    v.SB = reinterpret_cast<uint16_t *>(base + off); off += up((size_t)g * b_ring);
-    // pairs of a group lie back to back at the unpadded sizes the kernels index with; the rounded-up
-    // parts above only reserve room, so recompute the real extents for the clears
+    v.cl = reinterpret_cast<u32 *>(base + lay.cl);
+    v.cr = reinterpret_cast<u32 *>(base + lay.cr);
+    v.raw = reinterpret_cast<uint16_t *>(base + lay.raw);
+    v.E = base + lay.E;
+    v.BL = reinterpret_cast<uint16_t *>(base + lay.BL);
+    v.SB = reinterpret_cast<uint16_t *>(base + lay.SB);
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n; i += g) {
         const int k = n - i < g ? n - i : g;
@@ -1086,7 +1105,7 @@ int sgmx_compute_census_u8_batch(sgmx_ctx *c, int n, const uint8_t *left, const 
             e = hipStreamWaitEvent(st, c->ev_out[s], 0); // group g-2 has left this set's output buffer
         if (e != hipSuccess)
             break;
-        rc = census_group(c, count(g), dl[s], dr[s], dout[s], st);
+        rc = census_group(c, count(g), dl[s], dr[s], dout[s], st, g * B);
         if (rc)
             break;
         e = hipEventRecord(c->ev_done[s], st);
@@ -1196,6 +1215,7 @@ int sgmx_compute_cost_f32_dev(sgmx_ctx *c, int n, const float *d_cost, int W, in
         if (rc)
             return rc;
         c->last_n = g;
+        c->last_first = i;
         if ((rc = scratch_release(c, st)))
             return rc;
     }
@@ -1259,6 +1279,7 @@ int sgmx_compute_desc_f32(sgmx_ctx *c, const float *desc_left, const float *desc
         if (!rc)
             rc = run_wta_median(c, 1, true, c->d_out, st);
         c->last_n = 1;
+        c->last_first = 0;
         if (!rc)
             rc = scratch_release(c, st);
         if (!rc)
@@ -1297,7 +1318,7 @@ int sgmx_sgmstereo_cost_f32_dev(sgmx_ctx *c, int n, const float *d_cost, int W, 
                                (float *)c->d_C, c->Dp, (size_t)g * npix, 0.f);
             src = (const float *)c->d_C;
         }
-        if ((rc = ns_group(c, g, src, consistency_threshold, d_disp + i * npix, st)))
+        if ((rc = ns_group(c, g, src, consistency_threshold, d_disp + i * npix, st, i)))
             return rc;
     }
     return SGMX_OK;
@@ -2035,6 +2056,17 @@ int sgmx_get_data_cost_wta_u8(sgmx_ctx *c, int index, uint8_t *out)
     (void)hipFree(vol);
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, SGMX_ERR_HIP, std::string("data-cost WTA tap: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SGMX_OK;
+}
+
+int sgmx_last_launch_group(const sgmx_ctx *c, int *first_pair, int *count)
+{
+    if (!c)
+        return SGMX_ERR_INVALID_ARG;
+    if (first_pair)
+        *first_pair = c->last_first;
+    if (count)
+        *count = c->last_n;
     return SGMX_OK;
 }
 

@@ -12,6 +12,7 @@ reference asserts / throws / has undefined behaviour.  All arithmetic happens in
 libsgmx.so on the GPU; numpy is only used to hold host buffers.
 """
 import ctypes as C
+import math
 import struct
 from dataclasses import dataclass
 
@@ -90,6 +91,15 @@ class Engine:
             self.check(self.lib.sgmx_direction_stats(self.h, k, C.byref(ms), C.byref(n)))
             out.append((ms.value, n.value))
         return out
+
+    def last_launch_group(self):
+        """(first_pair, count): the pairs of the last compute call that the stage taps can reach -- `index` of
+        stages() / data_cost_image() counts from first_pair.  A call runs its pairs in launch groups of at most
+        max_batch pairs (the volume-free census path: also at most 32 pairs and 208 MB of census images), and the
+        scratch holds the last group only."""
+        first, count = C.c_int(0), C.c_int(0)
+        self.check(self.lib.sgmx_last_launch_group(self.h, C.byref(first), C.byref(count)))
+        return first.value, count.value
 
     def algorithmic_bytes(self, W, H):
         agg = C.c_double()
@@ -286,6 +296,8 @@ class StereoSGM(Engine):
         return k, h
 
     def stages(self, H, W, index=0):
+        """Stages of pair `index` of the LAST LAUNCH GROUP of the last call (not of the call: see
+        last_launch_group(), which says which pair of the call that is)."""
         m = self.margin
         h, w, D = H - 2 * m, W - 2 * m, self.params.disp_range
         Cv = np.empty((h, w, D), np.uint8)
@@ -386,8 +398,10 @@ class SGMStereo:
         if P1 >= P2:
             raise ValueError("small value of smoothness penalty must be smaller than large penalty value")
         # The reference keeps the penalties as float (sgm_stereo.h:63-64); this engine's parameter block is the
-        # four ints of StereoSGMParams, so fractional penalties are refused rather than silently truncated.
-        if float(P1) != int(P1) or float(P2) != int(P2):
+        # four ints of StereoSGMParams, so fractional penalties are refused rather than silently truncated
+        # (NaN passes both comparisons above, infinities the first: refused here, before any int()).
+        if not (math.isfinite(P1) and math.isfinite(P2)) or not (float(P1).is_integer() and float(P2).is_integer()) \
+                or P2 > 2 ** 31 - 1:
             raise ValueError("smoothness penalties must be whole numbers (sgmx_params holds ints)")
         self.P1, self.P2 = int(P1), int(P2)
 

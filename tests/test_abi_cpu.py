@@ -45,11 +45,15 @@ def _create(**kw):
 
 
 @pytest.mark.parametrize("kw", [dict(disp_range=1), dict(disp_range=513), dict(num_paths=5), dict(penalty1=-1),
-                                dict(window_sz=-3), dict(window_sz=4), dict(flags=4), dict(flags=2), dict(max_batch=-2),
+                                dict(window_sz=-3), dict(window_sz=4), dict(flags=4), dict(flags=8), dict(max_batch=-2),
                                 dict(device=64)])
 def test_create_rejects_bad_parameters(kw):
     rc, msg = _create(**kw)
     assert rc == 1 and msg  # SGMX_ERR_INVALID_ARG, with text
+
+
+def test_create_accepts_the_deprecated_flag():
+    assert _create(flags=2)[0] in (0, 3)  # SGMX_FLAG_NO_SMALL_GROUPS: accepted and ignored (NO_DEVICE here)
 
 
 def test_create_leaves_the_uint16_guard_to_the_census_calls():

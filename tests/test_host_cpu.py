@@ -288,6 +288,24 @@ def test_cli_fails_loudly_without_a_gpu(tmp_path):
     assert not list(tmp_path.iterdir())
 
 
+def test_adapter_refuses_non_finite_and_fractional_penalties(tmp_path):
+    """recon::SGMStereo::SetSmoothnessCostParameters (sgm_stereo.cc:16-28) in include/sgmx_recon.hpp: NaN, infinities,
+    values beyond int and fractions throw std::invalid_argument before any cast (no GPU call is made)."""
+    src = tmp_path / "p.cc"
+    src.write_text('#include <cmath>\n#include <cstdio>\n#include "sgmx_recon.hpp"\n'
+                   "int main() {\n"
+                   "  const double bad[][2] = {{3, INFINITY}, {NAN, 40}, {3, NAN}, {2.5, 40}, {3, 1e12}, {-1, 4}, {40, 3}};\n"
+                   "  int thrown = 0;\n"
+                   "  for (auto &b : bad) { recon::SGMStereo t; try { t.SetSmoothnessCostParameters(b[0], b[1]); }\n"
+                   "    catch (const std::invalid_argument &) { thrown++; } }\n"
+                   "  recon::SGMStereo ok; ok.SetSmoothnessCostParameters(3, 40);\n"
+                   '  std::printf("%d\\n", thrown); return thrown == 7 ? 0 : 1; }\n')
+    exe = tmp_path / "p"
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "stereo_vision_amd"), "-lsgmx", "-Wl,-rpath," + os.path.join(ROOT, "stereo_vision_amd")])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "7"
+
+
 def test_adapter_header_compiles_standalone(tmp_path):
     """include/sgmx_recon.hpp is self-contained C++11 and keeps the reference's signatures."""
     src = tmp_path / "t.cc"

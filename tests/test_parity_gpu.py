@@ -319,6 +319,35 @@ def test_batch_chunks_equal_single(oracle):
         assert np.array_equal(got[i], oracle.sgm_census(L[i], R[i], 64, 5, 3, 60, 8)), i
 
 
+def test_deprecated_flag_is_accepted(oracle):
+    """SGMX_FLAG_NO_SMALL_GROUPS (2) of the round-1 header is a no-op today; contexts created with it still work."""
+    left, right = synth_pair(5, 30, 90, 20)
+    e = make(disp_range=32, flags=2)
+    assert np.array_equal(e.compute(left, right), oracle.sgm_census(left, right, 32, 5, 3, 60, 8))
+    e.close()
+    with pytest.raises(sv.SgmxError):
+        make(disp_range=32, flags=4)
+
+
+def test_taps_address_the_last_launch_group(oracle):
+    """The stage taps reach the last launch group only; sgmx_last_launch_group says which pairs of the call those
+    are.  5 pairs with max_batch 2 run as 2 + 2 + 1: tap index 0 is pair 4 of the call."""
+    n, H, W = 5, 34, 120
+    pairs = [synth_pair(100 + i, H, W, 40) for i in range(n)]
+    e = make(disp_range=64, window_sz=5, max_batch=2)
+    e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+    assert e.last_launch_group() == (4, 1)
+    want = oracle.sgm_census(pairs[4][0], pairs[4][1], 64, 5, 3, 60, 8, taps=True)
+    assert np.array_equal(e.stages(H, W, 0)["S"], want["S"])
+    with pytest.raises(sv.SgmxError):
+        e.stages(H, W, 1)
+    e.compute_batch(np.stack([p[0] for p in pairs[:4]]), np.stack([p[1] for p in pairs[:4]]))
+    assert e.last_launch_group() == (2, 2)
+    want = oracle.sgm_census(pairs[3][0], pairs[3][1], 64, 5, 3, 60, 8, taps=True)
+    assert np.array_equal(e.stages(H, W, 1)["S"], want["S"])
+    e.close()
+
+
 def test_adaptive_groups_mix_formulations(oracle):
     """max_batch 5 over 9 pairs: a group of 5 then one of 4, then a single-pair call on the same
     context, and the stage taps of that call: all bit-exact."""

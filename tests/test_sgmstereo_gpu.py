@@ -138,6 +138,9 @@ def test_errors():
     e = sv.SGMStereo()
     with pytest.raises(ValueError):
         e.SetSmoothnessCostParameters(40, 3)  # sgm_stereo.cc:21-24
+    for bad in ((3, float("inf")), (float("nan"), 40), (3, float("nan")), (2.5, 40), (3, 1e12)):
+        with pytest.raises(ValueError, match="whole numbers|smaller than|less than zero"):
+            e.SetSmoothnessCostParameters(*bad)
     with pytest.raises(ValueError):
         e.SetConsistencyThreshold(-1)
     with pytest.raises(sv.SgmxError):

@@ -34,7 +34,8 @@ def test_noalloc_equals_dev_entry_point_two_calls_second_smaller(oracle):
     import torch
     import stereo_vision_amd as sv
     assert sv._lib.load().sgmx_noalloc_scratch_bytes() == 64 << 20
-    # first call: 3 pairs of 288x200 at D=64, 8 paths, in launch groups of 2 (19 MB per pair: 3 fit, max_batch caps at 2)
+    # first call: 3 pairs of 288x200 at D=64, 8 paths, in launch groups of 2 (29.4 MB per pair: 2 fit the 64 MiB, and
+    # max_batch is 2 as well)
     big = [synth_pair(700 + i, 200, 288, 50) for i in range(3)]
     got, want = _both(sv, torch, big, 64, 8, 2)
     assert np.array_equal(got, want)
@@ -67,3 +68,50 @@ def test_noalloc_limits_are_clear_errors():
         e.compute_device_noalloc(L.data_ptr(), L.data_ptr(), out.data_ptr(), 1, 64, 32, 0)
     assert ei.value.code == 1 and "volume-free" in str(ei.value)
     e.close()
+
+
+def test_noalloc_under_stream_capture_replays_equal_dev(oracle):
+    """The entry point's purpose: it may run where hipMalloc may not.  Two calls (the second with a smaller input and
+    another lane layout) are captured into one HIP graph on a side stream in GLOBAL capture mode -- an allocation, a
+    free or a synchronous copy anywhere in the process would invalidate the capture -- and the graph is replayed three
+    times on fresh outputs: every replay equals sgmx_compute_census_u8_dev and the oracle."""
+    import torch
+    import stereo_vision_amd as sv
+    big = [synth_pair(910 + i, 120, 200, 40) for i in range(2)]
+    small = [synth_pair(920 + i, 61, 97, 12) for i in range(2)]
+    eb = sv.StereoSGM(sv.StereoSGMParams(disp_range=64, window_sz=5, penalty1=3, penalty2=60, num_paths=8, max_batch=2))
+    es = sv.StereoSGM(sv.StereoSGMParams(disp_range=16, window_sz=5, penalty1=3, penalty2=60, num_paths=4, max_batch=2))
+    dev = lambda pairs, k: torch.from_numpy(np.stack([p[k] for p in pairs])).cuda()
+    Lb, Rb, Ls, Rs = dev(big, 0), dev(big, 1), dev(small, 0), dev(small, 1)
+    ob = torch.zeros((2, 120, 200), dtype=torch.int16, device="cuda")
+    os_ = torch.zeros((2, 61, 97), dtype=torch.int16, device="cuda")
+    wb, ws = torch.zeros_like(ob), torch.zeros_like(os_)
+    st0 = torch.cuda.current_stream().cuda_stream
+    for e, L, R, w_, (H, W) in ((eb, Lb, Rb, wb, (120, 200)), (es, Ls, Rs, ws, (61, 97))):
+        assert e.lib.sgmx_compute_census_u8_dev(e.h, 2, L.data_ptr(), R.data_ptr(), W, H, w_.data_ptr(), st0) == 0
+        # one eager call before the capture: the runtime loads a kernel's code object at its first launch
+        assert e.lib.sgmx_compute_census_u8_dev_noalloc(e.h, 2, L.data_ptr(), R.data_ptr(), W, H, w_.data_ptr(), st0) == 0
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="global"):
+        st = torch.cuda.current_stream().cuda_stream
+        rc1 = eb.lib.sgmx_compute_census_u8_dev_noalloc(eb.h, 2, Lb.data_ptr(), Rb.data_ptr(), 200, 120, ob.data_ptr(), st)
+        rc2 = es.lib.sgmx_compute_census_u8_dev_noalloc(es.h, 2, Ls.data_ptr(), Rs.data_ptr(), 97, 61, os_.data_ptr(), st)
+    assert rc1 == 0, eb.lib.sgmx_last_error(eb.h)
+    assert rc2 == 0, es.lib.sgmx_last_error(es.h)
+    assert torch.cuda.mem_get_info()[0] >= free_before - (8 << 20)  # (the graph object itself; no scratch was allocated)
+    for rep in range(3):
+        ob.fill_(-1)
+        os_.fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ob, wb) and torch.equal(os_, ws), "replay %d" % rep
+    got = ob.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got[1], oracle.sgm_census(big[1][0], big[1][1], 64, 5, 3, 60, 8))
+    gots = os_.cpu().numpy().view(np.uint16)
+    assert np.array_equal(gots[0], oracle.sgm_census(small[0][0], small[0][1], 16, 5, 3, 60, 4))
+    del graph
+    eb.close()
+    es.close()
