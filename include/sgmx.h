@@ -203,6 +203,13 @@ SGMX_API int sgmx_depth_from_disparity_u16(sgmx_ctx *ctx, const uint16_t *disp, 
 SGMX_API int sgmx_gaussian_blur3_u8(sgmx_ctx *ctx, const uint8_t *src, int W, int H, int stride_src, double sigma,
                                     uint8_t *dst, int stride_dst);
 
+/* The same pre-filter fused into the census entry points: once enabled, sgmx_compute_census_u8, _batch and _dev
+ * blur both images of every pair on the device (same arithmetic as sgmx_gaussian_blur3_u8, bit for bit) before
+ * the census transform -- what dense_stereo/main.cc:83-85 and stereo_eval/main.cc:36-38 do to every image on the
+ * host before compute(), without the two host round trips per pair.  sigma = 0: OpenCV's default for a 3x3
+ * kernel (0.8).  The no-allocation entry point refuses contexts with the pre-blur on. */
+SGMX_API int sgmx_set_preblur3(sgmx_ctx *ctx, int enabled, double sigma);
+
 /* ---- stage taps (host pointers; for parity tests and debugging) ---- */
 
 /* StereoCosts::census_transform (stereo_costs.cc:36-61): out is (H-2m) x (W-2m) uint32. */

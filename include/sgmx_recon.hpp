@@ -240,6 +240,13 @@ class StereoSGM {
     }
     void host_free(void *p) { (void)sgmx_host_free(ctx_.get(), p); }
 
+    // The callers' cv::GaussianBlur(img, img, cv::Size(3,3), sigma) (dense_stereo/main.cc:83-85,
+    // stereo_eval/main.cc:36-38) fused in front of the census transform of every compute call (extension).
+    void set_preblur(double sigma, bool enabled = true)
+    {
+        ctx_.check(sgmx_set_preblur3(ctx_.get(), enabled ? 1 : 0, sigma), "sgmx_set_preblur3");
+    }
+
     sgmx_ctx *handle() const { return ctx_.get(); }
     const StereoSGMParams &params() const { return params_; }
 

@@ -58,6 +58,7 @@ SYMBOLS = {
     "sgmx_get_stages_census": (_i, [_vp, _i, _vp, _vp, _vp]),
     "sgmx_get_stages_f32": (_i, [_vp, _i, _vp, _vp]),
     "sgmx_get_data_cost_wta_u8": (_i, [_vp, _i, _vp]),
+    "sgmx_set_preblur3": (_i, [_vp, _i, C.c_double]),
     "sgmx_last_launch_group": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sgmx_set_profiling": (_i, [_vp, _i]),
     "sgmx_kernel_stats": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),

@@ -111,6 +111,11 @@ struct sgmx_ctx {
     // device scratch (sized for max_batch pairs)
     uint8_t *d_left = nullptr, *d_right = nullptr; // staged inputs for the host entry points
     uint8_t *d_left2 = nullptr, *d_right2 = nullptr; // second staging set of the pipelined batch entry point
+    // sgmx_set_preblur3: the callers' 3x3 Gaussian pre-filter fused in front of the census transform
+    bool preblur = false;
+    int blur_k0 = 0, blur_k1 = 0; // the kernel's centre and side taps, 8 fractional bits
+    uint8_t *d_blur = nullptr;    // blurred left and right images of one launch group
+    size_t blur_cap = 0;
     unsigned char *h_stage = nullptr; // page-locked staging of the one-pair host entry point: left, right, disparity
     size_t h_stage_bytes = 0;
     uint16_t *d_out2 = nullptr;
@@ -168,7 +173,9 @@ void free_scratch(sgmx_ctx *c)
 {
     void *ptrs[] = {c->d_left, c->d_right, c->d_cl,  c->d_cr, c->d_C,  c->d_S,     c->d_BL,   c->d_raw,   c->d_out,
                     c->d_E,    c->d_SB,    c->d_C2,  c->d_sub, c->d_ld, c->d_rd,   c->d_label, c->d_size, c->d_states,
-                    c->d_left2, c->d_right2, c->d_out2};
+                    c->d_left2, c->d_right2, c->d_out2, c->d_blur};
+    c->d_blur = nullptr;
+    c->blur_cap = 0;
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -645,6 +652,26 @@ int fast_launch_pairs(const sgmx_ctx *c, int w, int h, int wp)
 int census_group(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, uint16_t *d_disp, hipStream_t st, int base = 0)
 {
     const int W = c->W, H = c->H, w = c->w, h = c->h;
+    if (c->preblur) {
+        // cv::GaussianBlur(img, img, Size(3,3), sigma) of the callers (dense_stereo/main.cc:83-85,
+        // stereo_eval/main.cc:36-38) on both images of every pair, on the device, before anything reads them
+        const size_t nb = (size_t)n * W * H;
+        if (c->blur_cap < 2 * nb) {
+            if (c->d_blur)
+                HIPCHK(c, hipStreamSynchronize(st)); // (an earlier group of this call may still read it)
+            (void)hipFree(c->d_blur);
+            c->d_blur = nullptr;
+            c->blur_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_blur, 2 * nb));
+            c->blur_cap = 2 * nb;
+        }
+        const dim3 grid((W + 255) / 256, H, n);
+        hipLaunchKernelGGL(gauss3_u8_kernel, grid, dim3(256), 0, st, dL, W, H, c->blur_k0, c->blur_k1, c->d_blur);
+        hipLaunchKernelGGL(gauss3_u8_kernel, grid, dim3(256), 0, st, dR, W, H, c->blur_k0, c->blur_k1, c->d_blur + nb);
+        HIPCHK(c, hipGetLastError());
+        dL = c->d_blur;
+        dR = c->d_blur + nb;
+    }
     if (c->fast) {
         // launches of at most fast_launch_pairs pairs, one after the other on the same scratch
         const int cap = fast_launch_pairs(c, w, h, c->wp);
@@ -971,6 +998,9 @@ int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *c, int n, const uint8_t *d_left
     if (!c->fast)
         return fail(c, SGMX_ERR_INVALID_ARG, "the no-allocation entry point serves the volume-free formulation only "
                                              "(penalty2 <= 255, no SGMX_FLAG_MATERIALIZE)");
+    if (c->preblur)
+        return fail(c, SGMX_ERR_INVALID_ARG, "the no-allocation entry point does not run the pre-blur of sgmx_set_preblur3 "
+                                             "(its buffer is allocated on demand)");
     const int m = (c->prm.window_sz - 1) / 2, w = W - 2 * m, h = H - 2 * m, wp = w + c->DpF;
     const size_t lds = wta3_lds_bytes(c->DpF, w);
     if (lds > 64 * 1024)
@@ -1476,13 +1506,9 @@ int sgmx_depth_from_disparity_u16(sgmx_ctx *c, const uint16_t *disp, int W, int 
     return SGMX_OK;
 }
 
-int sgmx_gaussian_blur3_u8(sgmx_ctx *c, const uint8_t *src, int W, int H, int stride_src, double sigma, uint8_t *dst,
-                           int stride_dst)
+// getGaussianKernel(3, sigma, CV_32F), then 8 fractional bits (see include/sgmx.h): centre tap k0, side taps k1
+static void gauss3_taps_q8(double sigma, int *k0, int *k1)
 {
-    if (!c || !src || !dst || W < 1 || H < 1 || stride_src < W || stride_dst < W)
-        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size / pitch");
-    HIPCHK(c, hipSetDevice(c->prm.device));
-    // getGaussianKernel(3, sigma, CV_32F), then 8 fractional bits (see include/sgmx.h)
     const double sx = sigma > 0 ? sigma : ((3 - 1) * 0.5 - 1) * 0.3 + 0.8;
     float kf[3];
     double sum = 0;
@@ -1492,7 +1518,27 @@ int sgmx_gaussian_blur3_u8(sgmx_ctx *c, const uint8_t *src, int W, int H, int st
         sum += kf[i];
     }
     sum = 1. / sum;
-    const int k0 = (int)std::lrint((double)(float)(kf[1] * sum) * 256.0), k1 = (int)std::lrint((double)(float)(kf[0] * sum) * 256.0);
+    *k0 = (int)std::lrint((double)(float)(kf[1] * sum) * 256.0);
+    *k1 = (int)std::lrint((double)(float)(kf[0] * sum) * 256.0);
+}
+
+int sgmx_set_preblur3(sgmx_ctx *c, int enabled, double sigma)
+{
+    if (!c || !(sigma >= 0.0) || !std::isfinite(sigma))
+        return fail(c, SGMX_ERR_INVALID_ARG, "null context or bad sigma");
+    c->preblur = enabled != 0;
+    gauss3_taps_q8(sigma, &c->blur_k0, &c->blur_k1);
+    return SGMX_OK;
+}
+
+int sgmx_gaussian_blur3_u8(sgmx_ctx *c, const uint8_t *src, int W, int H, int stride_src, double sigma, uint8_t *dst,
+                           int stride_dst)
+{
+    if (!c || !src || !dst || W < 1 || H < 1 || stride_src < W || stride_dst < W)
+        return fail(c, SGMX_ERR_INVALID_ARG, "null pointer or bad size / pitch");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    int k0, k1;
+    gauss3_taps_q8(sigma, &k0, &k1);
     uint8_t *d = nullptr;
     const size_t nb = (size_t)W * H;
     HIPCHK(c, hipMalloc((void **)&d, 2 * nb));

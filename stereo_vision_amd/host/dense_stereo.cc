@@ -6,15 +6,18 @@
 // disp_folder/img/disp_<n>.png (8-bit, saturated, histogram-equalised) and
 // disp_folder/mat/disp_<n>.yml (the CV_16U matrix).  What the reference hard-codes are options:
 // --disp-range --window-sz --p1 --p2 --paths --device --sigma (0 < sigma, or --no-blur) --no-yml.
-#include "cli_common.hpp"
-#include "host_util.hpp"
-#include "png_io.hpp"
+// The reference decodes, blurs, computes and writes one pair after the other; here the list runs through the batch
+// pipeline of sgm_batch (batch_pipeline.hpp): launch groups of --batch pairs (default: sized from the first image)
+// through sgmx_compute_census_u8_batch with the Gaussian pre-filter fused in front of the census transform on the
+// device (sgmx_set_preblur3), decoders and writers on --threads host threads beside the engine.  Same files, same
+// bytes.  --one-at-a-time keeps the reference's loop (one compute() per pair, blur through its own calls).
+#include "batch_pipeline.hpp"
 
 int main(int argc, char **argv)
 {
     return sgmx::cli::guarded("dense_stereo", [&]() {
         const sgmx::cli::Args a = sgmx::cli::parse(
-            argc, argv, {"help", "no-blur", "no-yml"},
+            argc, argv, {"help", "no-blur", "no-yml", "one-at-a-time"},
             {{'c', "config"}, {'s', "source_folder"}, {'d', "disp_folder"}, {'l', "imglist"}});
         const char *usage = "  --help\n  -c [ --config ] arg (=config.txt)  config filename\n"
                             "  -s [ --source_folder ] arg  folder with source\n  -d [ --disp_folder ] arg  folder for output\n"
@@ -55,29 +58,59 @@ int main(int argc, char **argv)
         p.disp_range = a.num("disp-range", 270);
         p.penalty1 = a.num("p1", 7);
         const double sigma = a.has("no-blur") ? 0.0 : std::atof(a.str("sigma", "0.7").c_str());
-        recon::StereoSGM sgm(p, a.num("device", 0), a.num("paths", 8));
         sgmx::host::mkdirs(output_folder + "img");
         sgmx::host::mkdirs(output_folder + "mat");
-        for (size_t i = 0; i + 1 < imagelist.size(); i += 2) {
-            std::cout << source_folder + imagelist[i] << "\n";
-            sgmx::Mat img_left = sgmx::png::read_gray8(source_folder + imagelist[i]);
-            sgmx::Mat img_right = sgmx::png::read_gray8(source_folder + imagelist[i + 1]);
-            if (!a.has("no-blur")) {
-                sgm.gaussian_blur3(img_left, sigma);
-                sgm.gaussian_blur3(img_right, sigma);
-            }
-            sgmx::Mat mat_disp;
-            sgm.compute(img_left, img_right, mat_disp);
-            // dense_stereo/main.cc:106-107: substr(9, size - 13) of "/image_0/000000.png" is "000000"
-            const std::string &nm = imagelist[i];
-            const std::string tag = nm.size() >= 14 ? nm.substr(9, nm.size() - 13) : sgmx::host::stem(nm);
+        const bool no_yml = a.has("no-yml");
+        // dense_stereo/main.cc:106-107: substr(9, size - 13) of "/image_0/000000.png" is "000000"
+        auto tag_of = [](const std::string &nm) { return nm.size() >= 14 ? nm.substr(9, nm.size() - 13) : sgmx::host::stem(nm); };
+        auto save = [&](const std::string &tag, const sgmx::Mat &mat_disp) {
             const std::string img_fname = output_folder + "img/disp_" + tag + ".png";
             const std::string mat_fname = output_folder + "mat/disp_" + tag + ".yml";
-            std::cout << "Saving: " << img_fname << "\n" << mat_fname << "\n----------------------\n";
             sgmx::png::write_gray(img_fname, sgmx::host::equalize_hist(sgmx::host::convert_to_u8(mat_disp, 1.0)), 9);
-            if (!a.has("no-yml") && !sgmx::host::write_yml_u16(mat_fname, "disparity_matrix", mat_disp))
+            if (!no_yml && !sgmx::host::write_yml_u16(mat_fname, "disparity_matrix", mat_disp))
                 throw std::runtime_error("cannot write " + mat_fname);
+        };
+        auto say = [&](const std::string &name) {
+            const std::string tag = tag_of(name);
+            std::cout << source_folder + name << "\n"
+                      << "Saving: " << output_folder + "img/disp_" + tag + ".png" << "\n"
+                      << output_folder + "mat/disp_" + tag + ".yml" << "\n----------------------\n";
+        };
+        const auto t0 = std::chrono::steady_clock::now();
+        long npairs = 0;
+        if (a.has("one-at-a-time")) {
+            recon::StereoSGM sgm(p, a.num("device", 0), a.num("paths", 8));
+            for (size_t i = 0; i + 1 < imagelist.size(); i += 2, npairs++) {
+                sgmx::Mat img_left = sgmx::png::read_gray8(source_folder + imagelist[i]);
+                sgmx::Mat img_right = sgmx::png::read_gray8(source_folder + imagelist[i + 1]);
+                if (!a.has("no-blur")) {
+                    sgm.gaussian_blur3(img_left, sigma);
+                    sgm.gaussian_blur3(img_right, sigma);
+                }
+                sgmx::Mat mat_disp;
+                sgm.compute(img_left, img_right, mat_disp);
+                say(imagelist[i]);
+                save(tag_of(imagelist[i]), mat_disp);
+            }
+        } else {
+            std::vector<sgmx::host::BatchItem> items;
+            for (size_t i = 0; i + 1 < imagelist.size(); i += 2)
+                items.push_back({source_folder + imagelist[i], source_folder + imagelist[i + 1], imagelist[i]});
+            int batch = a.num("batch", 0);
+            if (batch <= 0 && !items.empty())
+                batch = sgmx::host::default_batch(items[0].left, p.disp_range, a.num("paths", 8));
+            batch = (int)std::max<long>(1, std::min<long>(batch, (long)items.size()));
+            recon::StereoSGM sgm(p, a.num("device", 0), a.num("paths", 8), batch);
+            if (!a.has("no-blur"))
+                sgm.set_preblur(sigma);
+            const sgmx::host::BatchCounters r = sgmx::host::run_census_pipeline(
+                sgm, items, batch, std::max(1, a.num("threads", 16)),
+                [&](const sgmx::host::BatchItem &it) { say(it.prefix); },
+                [&](const sgmx::host::BatchItem &it, const sgmx::Mat &disp) { save(tag_of(it.prefix), disp); });
+            npairs = r.frames;
         }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::fprintf(stderr, "dense_stereo: %ld pairs in %.3f s = %.1f pairs/s\n", npairs, secs, npairs / std::max(secs, 1e-9));
         return 0;
     });
 }

@@ -122,6 +122,11 @@ def _gaussian_blur3(engine, img, sigma):
 class StereoSGM(Engine):
     """recon::StereoSGM (stereo_sgm.h:53-57), COST_CENSUS build."""
 
+    def set_preblur(self, sigma=0.7, enabled=True):
+        """cv::GaussianBlur(img, img, Size(3, 3), sigma) on both images of every pair, fused in front of the census
+        transform on the device (the callers' pre-filter: dense_stereo/main.cc:83-85, stereo_eval/main.cc:36-38)."""
+        self.check(self.lib.sgmx_set_preblur3(self.h, int(enabled), float(sigma)))
+
     def compute(self, left_img, right_img):
         """left/right: (H, W) uint8 (any row pitch) -> (H, W) uint16, 256 * disparity."""
         left_img, right_img = np.asarray(left_img), np.asarray(right_img)

@@ -103,6 +103,58 @@ def test_dense_stereo_binary(oracle, tmp_path):
                           np.array(Image.open(outdir + "img/disp_000001.png")))
 
 
+def test_dense_stereo_batch_pipeline_equals_one_at_a_time(oracle, tmp_path):
+    """dense_stereo runs its list through the batch pipeline (launch groups, pre-blur fused on the device, decoders
+    and writers beside the engine); --one-at-a-time keeps the loop of dense_stereo/main.cc:76-114.  Same files, same
+    bytes, for 5 pairs in groups of 2 at the reference's own disparity range (270: the 12-pairs-per-lane layout)."""
+    import filecmp
+    src = tmp_path / "seq"
+    (src / "image_0").mkdir(parents=True), (src / "image_1").mkdir()
+    names = []
+    for i in range(5):
+        l, r = synth_pair(60 + i, 36, 300, 120)
+        Image.fromarray(l).save(src / "image_0" / ("%06d.png" % i))
+        Image.fromarray(r).save(src / "image_1" / ("%06d.png" % i))
+        names += ["/image_0/%06d.png" % i, "/image_1/%06d.png" % i]
+    lst = tmp_path / "lst.xml"
+    lst.write_text('<?xml version="1.0"?>\n<opencv_storage>\n<imagelist>\n' + "\n".join('"%s"' % n for n in names) +
+                   "\n</imagelist>\n</opencv_storage>\n")
+    outs = []
+    for k, extra in enumerate((["--batch", 2], ["--one-at-a-time"], ["--batch", 3, "--no-blur"], ["--one-at-a-time", "--no-blur"])):
+        out = str(tmp_path / ("disp%d" % k)) + "/"
+        r = run("dense_stereo", "-s", src, "-d", out, "-l", lst, "-c", _empty_cfg(tmp_path), *extra)
+        assert r.stdout.count("Saving: ") == 5 and "pairs/s" in r.stderr
+        outs.append(out)
+    for a_, b_ in ((outs[0], outs[1]), (outs[2], outs[3])):
+        for i in range(5):
+            for f in ("img/disp_%06d.png" % i, "mat/disp_%06d.yml" % i):
+                assert filecmp.cmp(a_ + f, b_ + f, shallow=False), f
+    assert not filecmp.cmp(outs[0] + "mat/disp_000002.yml", outs[2] + "mat/disp_000002.yml", shallow=False)  # the blur matters
+
+
+def _empty_cfg(tmp_path):
+    c = tmp_path / "empty.txt"
+    c.write_text("start_num = 0\n")
+    return c
+
+
+def test_preblur_fused_equals_explicit_blur(oracle):
+    """sgmx_set_preblur3: the callers' GaussianBlur (dense_stereo/main.cc:83-85) in front of the census transform, on the
+    device, for the one-pair, the batch and the device entry points == blurring first (oracle) and computing."""
+    pairs = [synth_pair(90 + i, 33, 140, 40) for i in range(3)]
+    want = [oracle.sgm_census(oracle.gaussian3(l, 0.7), oracle.gaussian3(r, 0.7), 64, 5, 3, 60, 8) for l, r in pairs]
+    e = sv.StereoSGM(sv.StereoSGMParams(disp_range=64, window_sz=5, penalty1=3, penalty2=60, max_batch=2))
+    e.set_preblur(0.7)
+    assert np.array_equal(e.compute(*pairs[0]), want[0])
+    got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+    assert all(np.array_equal(got[i], want[i]) for i in range(3))
+    e.set_preblur(0.7, enabled=False)
+    assert np.array_equal(e.compute(*pairs[0]), oracle.sgm_census(pairs[0][0], pairs[0][1], 64, 5, 3, 60, 8))
+    e.set_preblur(0.0)  # OpenCV's default sigma for a 3x3 kernel
+    assert np.array_equal(e.compute(*pairs[1]), oracle.sgm_census(oracle.gaussian3(pairs[1][0], 0.0), oracle.gaussian3(pairs[1][1], 0.0), 64, 5, 3, 60, 8))
+    e.close()
+
+
 def test_stereo_eval_binary_prints_the_reference_timing_line(tmp_path):
     """stereo_eval: the 7 x 11 penalty grid of stereo_eval/main.cc:23-24, one timing line per point."""
     r = run("stereo_eval", os.path.join(G, "left_000087.png"), os.path.join(G, "right_000087.png"), tmp_path, "--no-write")
