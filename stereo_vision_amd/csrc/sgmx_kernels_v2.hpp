@@ -54,6 +54,7 @@ constexpr int E_STORE_AUX = SGMX_E_AUX; // cache policy bits of a buffer store: 
 #ifndef SGMX_WRAP
 #define SGMX_WRAP 1 // diagonal sweeps walk wrapped diagonals (0: one row per diagonal, A/B builds only)
 #endif
+typedef short ss2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -372,7 +373,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     //   unmasked steady state: Q = (P2 - E) + (32 - C)          (K = 32 + P2; 32 - C is a popcount too)
     //   steps with d > x costs / last steps:  Q = KM - L         (KM = 255 + 2 P2 >= every L there, + P2)
     //   start pixels:                         Q = sat(KS - L)    (KS = 0x7000 > every start value; pads -> 0)
-    const u32 KMp = (u32)(255 + 2 * a.P2) * 0x10001u, K32p = (u32)(32 + a.P2) * 0x10001u;
+    const u32 KMp = (u32)(255 + 2 * a.P2) * 0x10001u, K32p = (u32)(32 + a.P2) * 0x10001u, K255p = (u32)(255 + a.P2) * 0x10001u;
+    // Steady-state steps with d > x costs (MASK): Q = G + (255 - C) (K = 255 + P2): halves with d <= x get
+    // 223 + popcount(~(censL ^ censR)) = 255 - C on top of G, halves with d > x (C = 255) nothing.  Which halves are
+    // alive comes from ONE packed value per lane and step, alv = (tl, -th) as two int16 (tl = x - RP q, th = Dp-1 - RP q - x):
+    // register j's low half is alive iff j <= tl, its high half iff j >= th, i.e. iff the halves of
+    // (j - 1, -j - 1) - alv are negative -- a packed subtraction from a constant and a packed arithmetic shift.
+    // (All of it modulo 2^16: x and Dp stay far below 2^15, check_size.)
+    u32 alv0 = ((u32)tl0 & 0xFFFFu) | ((u32)(-th0) << 16);
 
     // ---- step 0, the start pixels: L_k = L_{k-1} + C; their E bytes are 0, the carry goes to SB
     u32 prior[RP];
@@ -477,6 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
                 xt -= a.dx * w;
                 tl0 -= a.dx * w;
                 th0 += a.dx * w;
+                alv0 = ((u32)tl0 & 0xFFFFu) | ((u32)(-th0) << 16);
                 voE += wrapE;
                 wstart = true;
             }
@@ -574,7 +583,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         for (int j = 0; j < RP; j++)
             e[j] = pk_max3(gq[j], j ? hh[j - 1] : hbelow, j < RP - 1 ? hh[j + 1] : habove);
         u32 Lv[RP] = {}; // the true path costs, where a ring store may need them
-        if (MASK) {
+        if constexpr (MASK && !SLOW) {
+            u32 ncl;
+            asm("v_not_b32 %0, %1" : "=v"(ncl) : "v"(clv));
+            const u32 alv = pk_add(alv0, ((u32)(t * a.dx) & 0xFFFFu) * 0x10001u);
+            const u32 c223 = 223u;
+#pragma unroll
+            for (int j = 0; j < RP; j++) {
+                u32 lo, hi, pc;
+                asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(lo) : "v"(wl[RP - 1 - j] ^ ncl), "s"(c223));
+                asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(hi) : "v"(wh[j] ^ ncl), "s"(c223));
+                asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(pc) : "v"(hi), "v"(lo));
+                const u32 cj = ((u32)(j - 1) & 0xFFFFu) | ((u32)(-j - 1) << 16);
+                const u32 alive = __builtin_bit_cast(u32, (ss2)(__builtin_bit_cast(ss2, pk_sub(cj, alv)) >> 15));
+                prior[j] = pk_add(e[j], pc & alive);
+                if (HAS_PAD)
+                    prior[j] &= padmask[j];
+                if (EDGE)
+                    Lv[j] = pk_sub(K255p, prior[j]);
+            }
+        } else if (MASK) {
             u32 c[RP];
             cost_from_census<RP, true>(wl, wh, clv, tl0 + t * a.dx, th0 - t * a.dx, c);
             u32 bl[RP] = {};
