@@ -854,8 +854,13 @@ int check_size(sgmx_ctx *c, int W, int H, bool census)
     if (W - 2 * m < 1 || H - 2 * m < 1)
         return fail(c, SGMX_ERR_INVALID_ARG, "image smaller than the census window");
     const int Dp = census && c->fast ? c->DpF : c->Dp;
-    if ((size_t)(W - 2 * m) * (H - 2 * m) * Dp >= (size_t)1 << 31)
+    // The sweeps address a pair's volume with 32-bit offsets: voffset + soffset reach the volume's size plus one
+    // backward walk over it plus the wrapped diagonals' bias of w + h pixels (sgmx_kernels_v2.hpp), i.e. up to
+    // (2 npix + 2 h) * Dp bytes, which has to stay below 2^32.
+    if (((size_t)(W - 2 * m) * (H - 2 * m) + (size_t)(W - 2 * m) + (size_t)(H - 2 * m)) * Dp >= (size_t)1 << 31)
         return fail(c, SGMX_ERR_INVALID_ARG, "cost volume of one pair exceeds 2^31 voxels");
+    if (W - 2 * m > 30000) // (the sweeps' alive masks are int16 arithmetic on x - d; the WTA's LDS tables end far below this)
+        return fail(c, SGMX_ERR_INVALID_ARG, "image wider than 30000 pixels");
     // dynamic LDS of the WTA kernel this call will launch (a workgroup may use all 160 KiB of a CU)
     const int w = W - 2 * m;
     const size_t lds = census ? (c->fast ? wta3_lds_bytes(c->DpF, w) : (size_t)w * 8) : (size_t)w * 16;
