@@ -359,7 +359,8 @@ int run_aggregation(sgmx_ctx *c, int n, bool f32, hipStream_t st, const void *Cv
         a.dy = order ? order[k][1] : (np == 8 ? DIRS8[k][1] : DIRS4[k][1]);
         a.P1 = c->prm.penalty1;
         a.P2 = c->prm.penalty2;
-        a.npaths = a.dy == 0 ? c->h : (a.dx == 0 ? c->w : c->w + c->h - 1);
+        a.wrap = SGMX_WRAP && a.dx != 0 && a.dy != 0; // diagonal sweeps: w wrapped diagonals (WrapWalk)
+        a.npaths = a.dy == 0 ? c->h : (a.dx == 0 || a.wrap ? c->w : c->w + c->h - 1);
         a.first = k == 0;
         const dim3 grid((a.npaths + 3) / 4, n);
         ProfScope ps(c, SGMX_K_AGGREGATE, st, k);

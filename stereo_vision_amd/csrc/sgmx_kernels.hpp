@@ -205,6 +205,29 @@ struct AggArgs {
     int P1, P2;
     int npaths;       // paths of this direction in one pair
     int first;        // 1: S = L (first direction), 0: S += L
+    int wrap;         // diagonal directions: 1 = npaths = w wrapped diagonals of length h (WrapWalk below)
+};
+
+// Wrapped diagonals for the one-path-per-wave kernels (the volume-free kernels' WRAP, sgmx_kernels_v2.hpp): a wave walks
+// the pixels ((c + t dx) mod w, y0 + t dy), t = 0 .. h-1 -- diagonal c and then, from the opposite image column on, the
+// diagonal that starts one row further: w equally long paths instead of w + h - 1 of lengths 1 .. min(w, h).  The pixel
+// before a wrap ends a diagonal (its L goes into the ring), the pixel after it starts one (L_{k-1} + C from the ring,
+// stereo_sgm.cc:201,236).  Everything here is wave-uniform.
+struct WrapWalk {
+    int w, dx, stride, back; // image width, column step, voxels per step, voxels a wrap takes back (dx * w * Dp)
+    bool on;
+    // one step on: column x and voxel offset off; true when the step wrapped (x is then the start column)
+    __device__ __forceinline__ bool advance(int &x, int &off) const
+    {
+        x += dx;
+        off += stride;
+        if (on && (x == w || x < 0)) {
+            x -= dx * w;
+            off -= back;
+            return true;
+        }
+        return false;
+    }
 };
 
 // Path p of direction (dx,dy): start pixel and length.  A pixel starts a path iff
@@ -326,10 +349,15 @@ __global__ __launch_bounds__(256) void aggregate_u16_kernel(const AggArgs a)
     uint16_t *Sf = static_cast<uint16_t *>(a.S) + (size_t)blockIdx.y * npix * Dp;
     uint16_t *BLf = static_cast<uint16_t *>(a.BL) + (size_t)blockIdx.y * (size_t)(2 * w + 2 * h) * Dp;
 
-    const PathGeom g = path_geometry(p, w, h, a.dx, a.dy);
+    PathGeom g = path_geometry(p, w, h, a.dx, a.dy);
+    if (a.wrap) {
+        g.x0 = p, g.y0 = a.dy > 0 ? 0 : h - 1, g.len = h, g.edge = false;
+    }
     const int len = g.len;
     const int stride = (a.dy * w + a.dx) * Dp; // voxels per step; one pair holds < 2^31 voxels
     const int off0 = (g.y0 * w + g.x0) * Dp;
+    const WrapWalk walk{w, a.dx, stride, a.dx * w * Dp, a.wrap != 0};
+    const int xend = a.dx > 0 ? w - 1 : 0;
 
     const u32 P1p = (u32)a.P1 * 0x10001u, P2p = (u32)a.P2 * 0x10001u;
     u32 padfloor[R];
@@ -367,32 +395,42 @@ __global__ __launch_bounds__(256) void aggregate_u16_kernel(const AggArgs a)
     // ---- steps 1 .. len-1; ring slot i holds a step t with (t-1) % PF == i
     CRaw<R> cq[PF];
     SRaw<R> sq[PF];
+    int xp = g.x0, op = off0; // column and voxel offset of the newest prefetched step
 #pragma unroll
     for (int i = 0; i < PF; i++) {
-        const int o = off0 + (1 + i < len ? 1 + i : len - 1) * stride;
-        cq[i] = load_c<R>(Cf + o + loff);
+        if (1 + i < len)
+            walk.advance(xp, op);
+        cq[i] = load_c<R>(Cf + op + loff);
         if (!FIRST)
-            sq[i] = load_s<R>(Sf + o + loff);
+            sq[i] = load_s<R>(Sf + op + loff);
     }
-    const int xl = g.x0 + (len - 1) * a.dx, yl = g.y0 + (len - 1) * a.dy; // last pixel
-    uint16_t *bl_last = BLf + (size_t)border_index(yl, xl, w, h) * Dp;
+    const int xl = g.x0 + (len - 1) * a.dx, yl = g.y0 + (len - 1) * a.dy; // last pixel (paths that do not wrap)
+    uint16_t *bl_last = BLf + (size_t)border_index(yl, a.wrap ? 0 : xl, w, h) * Dp;
 
-    int o = off0; // voxel offset of the current step, advanced by the step lambda
+    int o = off0, xc = g.x0; // voxel offset and column of the current step, advanced by the step lambda
     auto step = [&](int t, int i, bool prefetch) {
-        o += stride;
+        const bool started = walk.advance(xc, o); // wrapped: this pixel starts the next diagonal
         u32 c[R];
         unpack_c(cq[i], c);
         SRaw<R> s;
         if (!FIRST)
             s = sq[i];
         if (prefetch) { // stream the volume PF steps ahead
-            const int o2 = o + PF * stride;
-            cq[i] = load_c<R>(Cf + o2 + loff);
+            walk.advance(xp, op);
+            cq[i] = load_c<R>(Cf + op + loff);
             if (!FIRST)
-                sq[i] = load_s<R>(Sf + o2 + loff);
+                sq[i] = load_s<R>(Sf + op + loff);
         }
+        const int y = g.y0 + t * a.dy;
         u32 L[R];
-        path_step_u16<R>(prior, c, P1p, P2p, L);
+        if (started) { // buf += C on a start pixel (stereo_sgm.cc:201,236), as in step 0
+            const SRaw<R> bl = load_s<R>(BLf + (size_t)border_index(y, xc, w, h) * Dp + loff);
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                L[j] = pk_add(bl.v[j], c[j]);
+        } else {
+            path_step_u16<R>(prior, c, P1p, P2p, L);
+        }
         u32 sn[R];
 #pragma unroll
         for (int j = 0; j < R; j++) {
@@ -402,8 +440,11 @@ __global__ __launch_bounds__(256) void aggregate_u16_kernel(const AggArgs a)
             prior[j] = L[j];
         }
         store_s<R>(Sf + o + loff, sn);
-        if (g.edge) { // path along an image edge: every pixel feeds a later direction's start
-            const int x = g.x0 + t * a.dx, y = g.y0 + t * a.dy;
+        if (a.wrap) { // first or last pixel of a diagonal: a border pixel that feeds a later direction's start
+            if (started || xc == xend || t == len - 1)
+                store_s<R>(BLf + (size_t)border_index(y, xc, w, h) * Dp + loff, L);
+        } else if (g.edge) { // path along an image edge: every pixel feeds a later direction's start
+            const int x = g.x0 + t * a.dx;
             store_s<R>(BLf + (size_t)border_index(y, x, w, h) * Dp + loff, L);
         } else if (t == len - 1) {
             store_s<R>(bl_last + loff, L);
@@ -450,10 +491,15 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
     float *Sf = static_cast<float *>(a.S) + (size_t)blockIdx.y * npix * Dp;
     float *BLf = static_cast<float *>(a.BL) + (size_t)blockIdx.y * (size_t)(2 * w + 2 * h) * Dp;
 
-    const PathGeom g = path_geometry(p, w, h, a.dx, a.dy);
+    PathGeom g = path_geometry(p, w, h, a.dx, a.dy);
+    if (a.wrap) {
+        g.x0 = p, g.y0 = a.dy > 0 ? 0 : h - 1, g.len = h, g.edge = false;
+    }
     const int len = g.len;
     const int stride = (a.dy * w + a.dx) * Dp; // voxels per step; one pair holds < 2^31 voxels
     const int off0 = (g.y0 * w + g.x0) * Dp;
+    const WrapWalk walk{w, a.dx, stride, a.dx * w * Dp, a.wrap != 0};
+    const int xend = a.dx > 0 ? w - 1 : 0;
     const float P1f = (float)a.P1, P2f = (float)a.P2;
     const float inf = __builtin_inff();
 
@@ -498,29 +544,35 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
         return;
 
     fvec cq[PF], sq[PF];
+    int xp = g.x0, op = off0; // column and voxel offset of the newest prefetched step
 #pragma unroll
     for (int i = 0; i < PF; i++) {
-        const int o = off0 + (1 + i < len ? 1 + i : len - 1) * stride;
-        cq[i] = ldv(Cf + o + loff);
+        if (1 + i < len)
+            walk.advance(xp, op);
+        cq[i] = ldv(Cf + op + loff);
         if (!FIRST)
-            sq[i] = ldv(Sf + o + loff);
+            sq[i] = ldv(Sf + op + loff);
     }
-    const int xl = g.x0 + (len - 1) * a.dx, yl = g.y0 + (len - 1) * a.dy;
-    const size_t bl_last = (size_t)border_index(yl, xl, w, h) * Dp;
+    const int xl = g.x0 + (len - 1) * a.dx, yl = g.y0 + (len - 1) * a.dy; // last pixel (paths that do not wrap)
+    const size_t bl_last = (size_t)border_index(yl, a.wrap ? 0 : xl, w, h) * Dp;
 
-    int o = off0;
+    int o = off0, xc = g.x0;
     auto step = [&](int t, int i, bool prefetch) {
-        o += stride;
+        const bool started = walk.advance(xc, o); // wrapped: this pixel starts the next diagonal
         const fvec c = cq[i];
         fvec s;
         if (!FIRST)
             s = sq[i];
         if (prefetch) {
-            const int o2 = o + PF * stride;
-            cq[i] = ldv(Cf + o2 + loff);
+            walk.advance(xp, op);
+            cq[i] = ldv(Cf + op + loff);
             if (!FIRST)
-                sq[i] = ldv(Sf + o2 + loff);
+                sq[i] = ldv(Sf + op + loff);
         }
+        const int y = g.y0 + t * a.dy;
+        fvec blv;
+        if (started) // sum_vectors on a start pixel (sgm.h:95-102), as in step 0
+            blv = ld(BLf + (size_t)border_index(y, xc, w, h) * Dp + loff);
         const float left = __builtin_bit_cast(float, dpp<0x138>(__builtin_bit_cast(u32, inf), __builtin_bit_cast(u32, prior[N - 1])));
         const float right = __builtin_bit_cast(float, dpp<0x130>(__builtin_bit_cast(u32, inf), __builtin_bit_cast(u32, prior[0])));
         float mn = prior[0];
@@ -538,6 +590,8 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
             e = fminf(e, pv + P1f);
             e = fminf(e, nx + P1f);
             L[j] = c[j] + (e - mp);
+            if (started)
+                L[j] = blv[j] + c[j];
             if (HAS_PAD && (int)loff + j >= a.D)
                 L[j] = inf;
             sn[j] = FIRST ? L[j] : s[j] + L[j];
@@ -546,8 +600,11 @@ __global__ __launch_bounds__(256) void aggregate_f32_kernel(const AggArgs a)
         for (int j = 0; j < N; j++)
             prior[j] = L[j];
         stv(Sf + o + loff, sn);
-        if (g.edge) {
-            const int x = g.x0 + t * a.dx, y = g.y0 + t * a.dy;
+        if (a.wrap) { // first or last pixel of a diagonal
+            if (started || xc == xend || t == len - 1)
+                st(BLf + (size_t)border_index(y, xc, w, h) * Dp + loff, L);
+        } else if (g.edge) {
+            const int x = g.x0 + t * a.dx;
             st(BLf + (size_t)border_index(y, x, w, h) * Dp + loff, L);
         } else if (t == len - 1) {
             st(BLf + bl_last + loff, L);

@@ -224,11 +224,32 @@ def test_wrapped_diagonal_boundaries(oracle, D):
     for w, h in ((9, 9), (10, 9), (9, 10), (13, 30), (16, 33), (17, 17), (18, 70), (23, 8), (31, 12), (40, 41), (3, 20), (2, 9), (1, 7)):
         H, W = h + 4, w + 4
         pairs = [synth_pair(w * 37 + h * 5 + D + k, H, W, max(1, min(D, W // 2))) for k in range(3)]
-        e = make(disp_range=D, window_sz=5, penalty1=3, penalty2=60, max_batch=3)
-        got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
-        for k, (left, right) in enumerate(pairs):
-            assert np.array_equal(got[k], oracle.sgm_census(left, right, D, 5, 3, 60, 8)), "w=%d h=%d pair %d" % (w, h, k)
-        e.close()
+        want = [oracle.sgm_census(left, right, D, 5, 3, 60, 8) for left, right in pairs]
+        for flags in (0, 1):  # the volume-free kernels (WRAP) and the materialised ones (WrapWalk)
+            e = make(disp_range=D, window_sz=5, penalty1=3, penalty2=60, max_batch=3, flags=flags)
+            got = e.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+            for k in range(3):
+                assert np.array_equal(got[k], want[k]), "w=%d h=%d pair %d flags %d" % (w, h, k, flags)
+            e.close()
+
+
+@pytest.mark.parametrize("case", [(9, 9, 16), (30, 13, 64), (70, 18, 40), (41, 40, 128), (20, 3, 8), (130, 37, 100), (64, 200, 130)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_float_volume_wrapped_diagonals(oracle, case):
+    """Float volumes taller than wide, square and wider than tall: the diagonal sweeps of the one-path-per-wave kernels
+    walk wrapped diagonals with several wraps per path (WrapWalk, sgmx_kernels.hpp).  Summed costs bit-exact against
+    the restatement of sgm.cc:103-118,177-254, disparities apart from the reference's undefined pixels."""
+    H, W, D = case
+    C = _float_volume(H * 7 + W + D, H, W, D, True)
+    e = make(sv.SGM, disp_range=D, penalty1=3, penalty2=60, num_paths=8)
+    disp = e.compute_cost(C)
+    want = oracle.sgm_cost_f32(C, 3, 60, 8, taps=True)
+    S = e.stages(H, W)["S"]
+    finite = np.isfinite(want["S"])
+    assert np.array_equal(np.isfinite(S), finite)
+    assert np.array_equal(S[finite], want["S"][finite])
+    assert int(np.sum(disp != want["disp"])) <= 9 * want["n_undefined"]
+    e.close()
 
 
 @pytest.mark.parametrize("case", _random_configs(64, 777), ids=lambda c: "x".join(map(str, c)))
