@@ -141,6 +141,15 @@ def other_configs(sv, torch, device):
       tsukuba_4path -- configs[0]'s geometry on the GPU: 384x288, D=16, 4 paths, 64 pairs per step"""
     out = {}
 
+    def guarded(name):  # a leg that fails (e.g. no room for the 4K scratch) leaves its error instead of a figure
+        def deco(fn):
+            try:
+                fn()
+            except Exception as exc:  # noqa: BLE001
+                out[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            torch.cuda.empty_cache()
+        return deco
+
     def timed(fn, steps, warm):
         for _ in range(warm):
             fn()
@@ -155,87 +164,93 @@ def other_configs(sv, torch, device):
         return {k: round(v[0] / steps, 4) for k, v in eng.kernel_stats().items() if v[1]}
 
     # ---- float data-cost volumes
-    H, W, D, B, N = 376, 1241, 128, 8, 8
-    g = torch.Generator(device="cuda").manual_seed(7)
-    Cv = (torch.rand((B, H, W, D), device="cuda", generator=g) * 4).contiguous()
-    do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
-    e = sv.SGM(sv.SGMParams(disp_range=D, penalty1=3, penalty2=60, device=device, max_batch=B))
-    fn = lambda: e.compute_cost_device(Cv.data_ptr(), do.data_ptr(), B, W, H, 0)
-    timed(fn, 1, 2)
-    e.set_profiling(True)
-    steps = 10
-    dt = timed(fn, steps, 0)
-    dirs = e.direction_stats()
-    km = kernel_ms(e, steps)
-    e.set_profiling(False)
-    V = H * W * D
-    sweep_ms = sum(d[0] for d in dirs) / max(1, sum(d[1] for d in dirs))
-    sweep_bytes = V * B * (12 * N - 4) / N  # C read once per sweep; S written by the first sweep, read-modify-written by the others
-    out["float_volume"] = {
-        "workload": "float data-cost volumes %dx%dx%d, %d paths, P1=3, P2=60, %d volumes per step" % (W, H, D, N, B),
-        "volumes_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "dtype": "f32",
-        "model_bytes_per_voxel": 12 * N, "step_GBs": round(12 * N * V * B / dt / 1e9, 1),
-        "step_frac_of_peak": round(12 * N * V * B / dt / 1e9 / HBM_PEAK_GBS, 4),
-        "sweep": {"kernel": "aggregate_f32_kernel", "avg_launch_ms": round(sweep_ms, 4), "alg_bytes_per_launch": int(sweep_bytes),
-                  "achieved": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                  "frac": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                  "per_direction_ms": [round(d[0] / max(1, d[1]), 4) for d in dirs]},
-        "kernel_ms_per_step": km}
-    e.close()
-    del Cv, do, e
-    torch.cuda.empty_cache()
+    @guarded("float_volume")
+    def _float():
+        H, W, D, B, N = 376, 1241, 128, 8, 8
+        g = torch.Generator(device="cuda").manual_seed(7)
+        Cv = (torch.rand((B, H, W, D), device="cuda", generator=g) * 4).contiguous()
+        do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
+        e = sv.SGM(sv.SGMParams(disp_range=D, penalty1=3, penalty2=60, device=device, max_batch=B))
+        fn = lambda: e.compute_cost_device(Cv.data_ptr(), do.data_ptr(), B, W, H, 0)
+        timed(fn, 1, 2)
+        e.set_profiling(True)
+        steps = 10
+        dt = timed(fn, steps, 0)
+        dirs = e.direction_stats()
+        km = kernel_ms(e, steps)
+        e.set_profiling(False)
+        V = H * W * D
+        sweep_ms = sum(d[0] for d in dirs) / max(1, sum(d[1] for d in dirs))
+        sweep_bytes = V * B * (12 * N - 4) / N  # C read once per sweep; S written by the first sweep, read-modify-written by the others
+        out["float_volume"] = {
+            "workload": "float data-cost volumes %dx%dx%d, %d paths, P1=3, P2=60, %d volumes per step" % (W, H, D, N, B),
+            "volumes_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "dtype": "f32",
+            "model_bytes_per_voxel": 12 * N, "step_GBs": round(12 * N * V * B / dt / 1e9, 1),
+            "step_frac_of_peak": round(12 * N * V * B / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "sweep": {"kernel": "aggregate_f32_kernel", "avg_launch_ms": round(sweep_ms, 4), "alg_bytes_per_launch": int(sweep_bytes),
+                      "achieved": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                      "frac": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "per_direction_ms": [round(d[0] / max(1, d[1]), 4) for d in dirs]},
+            "kernel_ms_per_step": km}
+        e.close()
+        del Cv, do, e
+        torch.cuda.empty_cache()
 
     # ---- 3840x2160, D = 256
-    H, W, D, B = 2160, 3840, 256, 8
-    pairs = [synthetic_pair(7 + i, H, W, 240) for i in range(2)]
-    L = torch.from_numpy(np.stack([pairs[i % 2][0] for i in range(B)])).cuda()
-    R = torch.from_numpy(np.stack([pairs[i % 2][1] for i in range(B)])).cuda()
-    do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
-    e = sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=5, penalty1=3, penalty2=60, device=device, max_batch=B))
-    fn = lambda: e.compute_device(L.data_ptr(), R.data_ptr(), do.data_ptr(), B, W, H, 0)
-    timed(fn, 1, 1)
-    e.set_profiling(True)
-    steps = 4
-    dt = timed(fn, steps, 0)
-    dirs = e.direction_stats()
-    km = kernel_ms(e, steps)
-    e.set_profiling(False)
-    h_, w_, Dp = H - 4, W - 4, 256
-    pair_bytes = h_ * w_ * Dp + h_ * w_ * 4 + h_ * (w_ + Dp) * 4 + 4 * (2 * w_ + 2 * h_) * Dp * 2  # as `roofline` below
-    sweeps_ms = sum(d[0] for d in dirs) / steps  # all sweeps of one step (8 pairs)
-    out["uhd_4k"] = {
-        "workload": "census/Hamming SGM %dx%d, D=%d, 8 paths, wsz=5, P1=3, P2=60, %d pairs per call" % (W, H, D, B),
-        "frames_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 2), "mde_per_s": round(B / dt * W * H * D / 1e6, 1),
-        "dtype": "u16",
-        "sweep": {"kernel": "aggregate3_kernel", "per_direction_ms_per_%d_pairs" % B: [round(d[0] / steps, 3) for d in dirs],
-                  "launches_per_direction_per_step": dirs[0][1] // steps,
-                  "alg_bytes_per_direction": int(B * pair_bytes),
-                  "achieved": round(8 * B * pair_bytes / (sweeps_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                  "frac": round(8 * B * pair_bytes / (sweeps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-        "kernel_ms_per_step": km}
-    e.close()
-    del L, R, do, e
-    torch.cuda.empty_cache()
+    @guarded("uhd_4k")
+    def _uhd():
+        H, W, D, B = 2160, 3840, 256, 8
+        pairs = [synthetic_pair(7 + i, H, W, 240) for i in range(2)]
+        L = torch.from_numpy(np.stack([pairs[i % 2][0] for i in range(B)])).cuda()
+        R = torch.from_numpy(np.stack([pairs[i % 2][1] for i in range(B)])).cuda()
+        do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
+        e = sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=5, penalty1=3, penalty2=60, device=device, max_batch=B))
+        fn = lambda: e.compute_device(L.data_ptr(), R.data_ptr(), do.data_ptr(), B, W, H, 0)
+        timed(fn, 1, 1)
+        e.set_profiling(True)
+        steps = 4
+        dt = timed(fn, steps, 0)
+        dirs = e.direction_stats()
+        km = kernel_ms(e, steps)
+        e.set_profiling(False)
+        h_, w_, Dp = H - 4, W - 4, 256
+        pair_bytes = h_ * w_ * Dp + h_ * w_ * 4 + h_ * (w_ + Dp) * 4 + 4 * (2 * w_ + 2 * h_) * Dp * 2  # as `roofline` below
+        sweeps_ms = sum(d[0] for d in dirs) / steps  # all sweeps of one step (8 pairs)
+        out["uhd_4k"] = {
+            "workload": "census/Hamming SGM %dx%d, D=%d, 8 paths, wsz=5, P1=3, P2=60, %d pairs per call" % (W, H, D, B),
+            "frames_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 2), "mde_per_s": round(B / dt * W * H * D / 1e6, 1),
+            "dtype": "u16",
+            "sweep": {"kernel": "aggregate3_kernel", "per_direction_ms_per_%d_pairs" % B: [round(d[0] / steps, 3) for d in dirs],
+                      "launches_per_direction_per_step": dirs[0][1] // steps,
+                      "alg_bytes_per_direction": int(B * pair_bytes),
+                      "achieved": round(8 * B * pair_bytes / (sweeps_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                      "frac": round(8 * B * pair_bytes / (sweeps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "kernel_ms_per_step": km}
+        e.close()
+        del L, R, do, e
+        torch.cuda.empty_cache()
 
     # ---- Tsukuba geometry, 4 paths
-    H, W, D, B = 288, 384, 16, 64
-    pairs = [synthetic_pair(3 + i, H, W, 12) for i in range(4)]
-    L = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).cuda()
-    R = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).cuda()
-    do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
-    e = sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=5, penalty1=3, penalty2=60, num_paths=4, device=device, max_batch=B))
-    fn = lambda: e.compute_device(L.data_ptr(), R.data_ptr(), do.data_ptr(), B, W, H, 0)
-    timed(fn, 1, 3)
-    e.set_profiling(True)
-    steps = 50
-    dt = timed(fn, steps, 0)
-    km = kernel_ms(e, steps)
-    e.set_profiling(False)
-    out["tsukuba_4path"] = {
-        "workload": "census/Hamming SGM %dx%d, D=%d, 4 paths, wsz=5, P1=3, P2=60, %d pairs per step" % (W, H, D, B),
-        "frames_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mde_per_s": round(B / dt * W * H * D / 1e6, 1),
-        "dtype": "u16", "kernel_ms_per_step": km}
-    e.close()
+    @guarded("tsukuba_4path")
+    def _tsukuba():
+        H, W, D, B = 288, 384, 16, 64
+        pairs = [synthetic_pair(3 + i, H, W, 12) for i in range(4)]
+        L = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).cuda()
+        R = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).cuda()
+        do = torch.zeros((B, H, W), dtype=torch.int16, device="cuda")
+        e = sv.StereoSGM(sv.StereoSGMParams(disp_range=D, window_sz=5, penalty1=3, penalty2=60, num_paths=4, device=device, max_batch=B))
+        fn = lambda: e.compute_device(L.data_ptr(), R.data_ptr(), do.data_ptr(), B, W, H, 0)
+        timed(fn, 1, 3)
+        e.set_profiling(True)
+        steps = 50
+        dt = timed(fn, steps, 0)
+        km = kernel_ms(e, steps)
+        e.set_profiling(False)
+        out["tsukuba_4path"] = {
+            "workload": "census/Hamming SGM %dx%d, D=%d, 4 paths, wsz=5, P1=3, P2=60, %d pairs per step" % (W, H, D, B),
+            "frames_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mde_per_s": round(B / dt * W * H * D / 1e6, 1),
+            "dtype": "u16", "kernel_ms_per_step": km}
+        e.close()
     return out
 
 
@@ -523,13 +538,19 @@ def main():
                                                           "sample": "%d frames, one per core" % ncore}
         out["cpu_baseline"] = cpu
         if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_figures(eng, sv, args, Lh, Rh, B, W, H)
+            # the legs beside the headline never take the line down with them: a failure is recorded in its place
+            def leg(name, fn):
+                try:
+                    return fn()
+                except Exception as exc:  # noqa: BLE001
+                    return {name + "_error": "%s: %s" % (type(exc).__name__, exc)}
+            out["secondary"] = leg("secondary", lambda: secondary_figures(eng, sv, args, Lh, Rh, B, W, H))
             if not args.no_other_configs:
                 eng.close()
                 del dL, dR, dO
                 torch.cuda.empty_cache()
-                out["secondary"].update(other_configs(sv, torch, local_rank))
-                out["secondary"]["hamming_library"] = hamming_library_leg(sv, local_rank)
+                out["secondary"].update(leg("other_configs", lambda: other_configs(sv, torch, local_rank)))
+                out["secondary"]["hamming_library"] = leg("hamming_library", lambda: hamming_library_leg(sv, local_rank))
         print(json.dumps(out), flush=True)
 
     if use_dist:
