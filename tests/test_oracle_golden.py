@@ -258,3 +258,30 @@ def test_hamming_allocating_and_threaded_forms_vs_reference_build(oracle, ncodes
     k, h = oracle.match_hamming_blocked(a, b, ht)
     rk, rh = oracle.ref_match_hamming_thres_nt(a, b, ht)
     assert len(h) > 0 and np.array_equal(rk, k) and np.array_equal(rh, h)
+
+
+def _cost_volume_from_reference_hamming(oracle, cl, cr, D):
+    """The data-cost loop of stereo_sgm.cc:75-101 with its popcount done by the reference's own compiled
+    core/hamming.c: compute_hamming on the 4-byte census codes of one image row gives popcount(cL[i] ^ cR[j]) for every
+    (i, j); C[y][x][d] is the entry (i, j) = (x, x - d) for d <= x and 255 (stereo_sgm.cc:43) otherwise."""
+    h, w = cl.shape
+    C = np.full((h, w, D), 255, np.uint8)
+    for y in range(h):
+        dis = oracle.ref_hamming_matrix(cl[y].view(np.uint8).reshape(w, 4), cr[y].view(np.uint8).reshape(w, 4))  # [j][i]
+        if dis is None:
+            return None
+        for d in range(min(D, w)):
+            xs = np.arange(d, w)
+            C[y, xs, d] = dis[xs - d, xs]
+    return C
+
+
+def test_data_cost_volume_vs_reference_popcount(oracle, tsukuba):
+    """the restatement's Hamming data-cost volume on the census codes of the reference's own
+    Tsukuba fixture equals the volume built with core/hamming.c's compute_hamming (reference build, oracle/_ref)."""
+    left, right = tsukuba
+    cl, cr = oracle.census(left[100:112], 5), oracle.census(right[100:112], 5)
+    want = _cost_volume_from_reference_hamming(oracle, np.ascontiguousarray(cl), np.ascontiguousarray(cr), 16)
+    if want is None:
+        pytest.skip("oracle/_ref/libhamming_ref.so not built (reference tree not mounted)")
+    assert np.array_equal(oracle.hamming_volume(cl, cr, 16), want)

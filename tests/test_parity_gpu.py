@@ -35,6 +35,21 @@ def test_hamming_volume_tap(oracle, D):
     assert np.array_equal(e.hamming_volume(cl, cr), oracle.hamming_volume(cl, cr, D))
 
 
+def test_hamming_volume_tap_vs_reference_popcount(oracle, tsukuba):
+    """The GPU's data-cost volume (stereo_sgm.cc:43,75-101) on the census codes of the reference's Tsukuba fixture against
+    the volume whose popcounts come from the reference's own compiled core/hamming.c (oracle/_ref)."""
+    from test_oracle_golden import _cost_volume_from_reference_hamming
+    left, right = tsukuba
+    e = make(disp_range=16)
+    cl = np.ascontiguousarray(e.census(left[90:120]))
+    cr = np.ascontiguousarray(e.census(right[90:120]))
+    want = _cost_volume_from_reference_hamming(oracle, cl, cr, 16)
+    if want is None:
+        pytest.skip("oracle/_ref/libhamming_ref.so not built (reference tree not mounted)")
+    assert np.array_equal(e.hamming_volume(cl, cr), want)
+    e.close()
+
+
 @pytest.mark.parametrize("ncodes", [4, 8, 16, 5, 32])
 def test_hamming_matrix(oracle, ncodes):
     rng = np.random.default_rng(ncodes)
