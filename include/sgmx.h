@@ -319,10 +319,15 @@ enum {
     SGMX_K_COUNT = 6
 };
 
-/* When enabled every kernel launch is bracketed by HIP events on the launch
- * stream; sgmx_kernel_stats synchronises, returns the accumulated duration and
- * launch count of one kernel class and clears them. */
-SGMX_API int sgmx_set_profiling(sgmx_ctx *ctx, int enabled);
+/* SGMX_PROFILE_ALL (1): every kernel launch is bracketed by two HIP events on the launch
+ * stream.  SGMX_PROFILE_SWEEPS (2): only the direction sweeps of the volume-free census path, and the sweeps of a
+ * launch group share their boundary events (9 markers per group of 8 sweeps instead of 26 for all its kernels:
+ * at KITTI size the markers of mode 1 cost 1.4 % of a step, those of mode 2 a third of that); the other classes
+ * then report nothing.  0: off.  sgmx_kernel_stats synchronises, returns the accumulated
+ * duration and launch count of one kernel class and clears them. */
+#define SGMX_PROFILE_ALL 1
+#define SGMX_PROFILE_SWEEPS 2
+SGMX_API int sgmx_set_profiling(sgmx_ctx *ctx, int mode);
 SGMX_API int sgmx_kernel_stats(sgmx_ctx *ctx, int kernel_class, double *total_ms, long *launches);
 /* The SGMX_K_AGGREGATE time again, split by direction: k = index of the direction in the schedule (8 paths: the
  * order of stereo_sgm.cc:120-122, (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1) as (DIRX, DIRY); 4 paths:

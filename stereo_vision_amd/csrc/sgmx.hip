@@ -33,6 +33,7 @@ struct ProfRec {
     int cls;
     int dir; // direction sweeps: index of the direction in the schedule, else -1
     hipEvent_t a, b;
+    bool owns_a; // false: a is the previous record's b (SGMX_PROFILE_SWEEPS chains the sweeps of a launch group)
 };
 
 // Device buffers and geometry of one census launch group in the volume-free formulation.  The context's own
@@ -142,7 +143,7 @@ struct sgmx_ctx {
     size_t ham_cap[HAM_SLOTS] = {0};
 
     hipStream_t own_stream = nullptr;
-    bool profiling = false;
+    int profiling = 0; // 0, SGMX_PROFILE_ALL or SGMX_PROFILE_SWEEPS
     std::vector<ProfRec> prof;
     double prof_ms[SGMX_K_COUNT] = {0};
     long prof_n[SGMX_K_COUNT] = {0};
@@ -283,11 +284,12 @@ struct ProfScope {
     hipStream_t st;
     ProfRec r;
     bool on;
-    ProfScope(sgmx_ctx *c_, int cls, hipStream_t s, int dir = -1) : c(c_), st(s), on(c_->profiling)
+    ProfScope(sgmx_ctx *c_, int cls, hipStream_t s, int dir = -1) : c(c_), st(s), on(c_->profiling == SGMX_PROFILE_ALL)
     {
         if (on) {
             r.cls = cls;
             r.dir = dir;
+            r.owns_a = true;
             on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess;
             if (on)
                 (void)hipEventRecord(r.a, st);
@@ -498,12 +500,12 @@ FastView ctx_view(const sgmx_ctx *c)
 int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_t st, bool prof)
 {
     const int np = c->prm.num_paths;
-    const bool was_profiling = c->profiling;
+    const int was_profiling = c->profiling;
     if (!prof)
-        c->profiling = false;
+        c->profiling = 0;
     struct Restore {
         sgmx_ctx *c;
-        bool v;
+        int v;
         ~Restore() { c->profiling = v; }
     } restore{c, was_profiling};
     HIPCHK(c, hipMemsetAsync(v.BL, 0, v.bytes_BL * n, st)); // path buffer starts at zero (stereo_sgm.cc:46)
@@ -517,6 +519,11 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
         HIPCHK(c, hipGetLastError());
     }
     const bool pad = c->prm.disp_range != c->DpF;
+    // SGMX_PROFILE_SWEEPS: the sweeps of the group share their boundary events (np + 1 markers on the stream
+    // instead of two per launch of every kernel class)
+    hipEvent_t chain = nullptr;
+    if (c->profiling == SGMX_PROFILE_SWEEPS && hipEventCreate(&chain) == hipSuccess)
+        (void)hipEventRecord(chain, st);
     for (int k = 0; k < np; k++) {
         Agg2Args a;
         a.w = v.w;
@@ -547,6 +554,18 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
             le = launch_agg3<12>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
         else
             le = launch_agg3<16>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
+        if (chain) {
+            hipEvent_t next = nullptr;
+            if (hipEventCreate(&next) == hipSuccess) {
+                (void)hipEventRecord(next, st);
+                c->prof.push_back(ProfRec{SGMX_K_AGGREGATE, k, chain, next, k == 0});
+                chain = next;
+            } else {
+                if (k == 0)
+                    (void)hipEventDestroy(chain);
+                chain = nullptr;
+            }
+        }
         HIPCHK(c, le);
         HIPCHK(c, hipGetLastError());
     }
@@ -613,9 +632,9 @@ int run_census(sgmx_ctx *c, int n, const uint8_t *dL, const uint8_t *dR, int W, 
                hipStream_t st, bool prof)
 {
     const int m = (c->prm.window_sz - 1) / 2, w = W - 2 * m, h = H - 2 * m;
-    const bool was_profiling = c->profiling;
+    const int was_profiling = c->profiling;
     if (!prof)
-        c->profiling = false;
+        c->profiling = 0;
     {
         ProfScope ps(c, SGMX_K_CENSUS, st);
         const dim3 g4((w + 1023) / 1024, h, 2 * n);
@@ -945,7 +964,8 @@ void sgmx_destroy(sgmx_ctx *ctx)
     (void)hipSetDevice(ctx->prm.device);
     (void)hipDeviceSynchronize();
     for (auto &r : ctx->prof) {
-        (void)hipEventDestroy(r.a);
+        if (r.owns_a)
+            (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     free_scratch(ctx);
@@ -2126,7 +2146,9 @@ int sgmx_set_profiling(sgmx_ctx *c, int enabled)
 {
     if (!c)
         return SGMX_ERR_INVALID_ARG;
-    c->profiling = enabled != 0;
+    if (enabled < 0 || enabled > SGMX_PROFILE_SWEEPS)
+        return fail(c, SGMX_ERR_INVALID_ARG, "bad profiling mode");
+    c->profiling = enabled;
     return SGMX_OK;
 }
 
@@ -2145,7 +2167,11 @@ static int collect_profile(sgmx_ctx *c)
                 c->prof_dir_n[r.dir] += 1;
             }
         }
-        (void)hipEventDestroy(r.a);
+    }
+    // (only now: in the chained mode a record's first event is the previous record's second one)
+    for (auto &r : c->prof) {
+        if (r.owns_a)
+            (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     c->prof.clear();

@@ -239,25 +239,36 @@ def sgm_cnn(left_desc_path, right_desc_path, out_dir, prefix, P1, P2, disp_range
 
 
 def dense_stereo(imagelist, source_folder, output_folder, disp_range=270, window_sz=5, P1=7, P2=60, sigma=0.7, device=0,
-                 write_yml=False):
+                 write_yml=False, batch=8):
     """runDenseStereo (dense_stereo/main.cc:42-118): left/right names alternate in `imagelist`; both
     images are Gaussian-blurred (:83-85), run through StereoSGM with the mains' hard-coded parameters
     (:87-97) and saved as output_folder/img/disp_<n>.png (8-bit, saturated, equalised).  Returns the
-    list of disparity maps."""
+    list of disparity maps.  The reference handles one pair after the other; here `batch` pairs go through one
+    compute_batch call with the pre-filter fused in front of the census transform on the device (set_preblur),
+    like the dense_stereo program (stereo_vision_amd/host/dense_stereo.cc) -- same results."""
     from PIL import Image
-    eng = StereoSGM(StereoSGMParams(disp_range=disp_range, window_sz=window_sz, penalty1=P1, penalty2=P2, device=device))
+    batch = max(1, int(batch))
+    eng = StereoSGM(StereoSGMParams(disp_range=disp_range, window_sz=window_sz, penalty1=P1, penalty2=P2, device=device,
+                                    max_batch=batch))
+    if sigma is not None:
+        eng.set_preblur(sigma)
     os.makedirs(output_folder + "img", exist_ok=True)
     os.makedirs(output_folder + "mat", exist_ok=True)
+    starts = list(range(0, len(imagelist) - 1, 2))
     out = []
-    for i in range(0, len(imagelist) - 1, 2):
-        left, right = (read_gray(source_folder + imagelist[k]) for k in (i, i + 1))
-        if sigma is not None:
-            left, right = eng.gaussian_blur3(left, sigma), eng.gaussian_blur3(right, sigma)
-        disp = eng.compute(left, right)
-        nm = imagelist[i]
-        tag = nm[9:len(nm) - 4] if len(nm) >= 14 else stem(nm)  # substr(9, size - 13), :106
-        Image.fromarray(equalize_hist(np.minimum(disp, 255).astype(np.uint8))).save(output_folder + "img/disp_" + tag + ".png")
-        out.append(disp)
+    for g in range(0, len(starts), batch):
+        chunk = starts[g:g + batch]
+        pairs = [tuple(read_gray(source_folder + imagelist[k]) for k in (i, i + 1)) for i in chunk]
+        if len({p[0].shape for p in pairs} | {p[1].shape for p in pairs}) == 1:
+            disps = list(eng.compute_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])))
+        else:  # sizes differ inside the chunk: one call per pair
+            disps = [eng.compute(l, r) for l, r in pairs]
+        for i, disp in zip(chunk, disps):
+            nm = imagelist[i]
+            tag = nm[9:len(nm) - 4] if len(nm) >= 14 else stem(nm)  # substr(9, size - 13), :106
+            Image.fromarray(equalize_hist(np.minimum(disp, 255).astype(np.uint8))).save(output_folder + "img/disp_" + tag + ".png")
+            out.append(disp)
+    eng.close()
     return out
 
 

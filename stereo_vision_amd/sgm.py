@@ -73,6 +73,8 @@ class Engine:
 
     # ---- measurement ----
     def set_profiling(self, on):
+        """False / 0: off; True / 1: two HIP events around every kernel launch; 2: the direction sweeps of the volume-free
+        census path only, with shared boundary events (the light mode bench.py times its headline under)."""
         self.check(self.lib.sgmx_set_profiling(self.h, int(on)))
 
     def kernel_stats(self):

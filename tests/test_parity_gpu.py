@@ -365,6 +365,30 @@ def test_deprecated_flag_is_accepted(oracle):
         make(disp_range=32, flags=4)
 
 
+def test_profiling_modes(oracle):
+    """sgmx_set_profiling: 1 brackets every launch (all classes report), 2 only the direction sweeps with shared boundary
+    events (per-direction times, the other classes report nothing); the results do not change."""
+    pairs = [synth_pair(300 + i, 40, 160, 40) for i in range(3)]
+    L, R = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    e = make(disp_range=64, window_sz=5, max_batch=3)
+    want = e.compute_batch(L, R)
+    for mode, classes in ((1, {"census", "aggregate", "wta", "median"}), (2, {"aggregate"})):
+        e.set_profiling(mode)
+        for _ in range(2):
+            assert np.array_equal(e.compute_batch(L, R), want)
+        dirs = e.direction_stats()
+        stats = e.kernel_stats()
+        assert {k for k, v in stats.items() if v[1]} == classes
+        assert stats["aggregate"][1] == 16 and all(n == 2 and ms > 0 for ms, n in dirs)
+        assert abs(sum(ms for ms, _ in dirs) - stats["aggregate"][0]) < 1e-6
+    e.set_profiling(0)
+    e.compute_batch(L, R)
+    assert all(v[1] == 0 for v in e.kernel_stats().values())
+    with pytest.raises(sv.SgmxError):
+        e.set_profiling(3)
+    e.close()
+
+
 def test_taps_address_the_last_launch_group(oracle):
     """The stage taps reach the last launch group only; sgmx_last_launch_group says which pairs of the call those
     are.  5 pairs with max_batch 2 run as 2 + 2 + 1: tap index 0 is pair 4 of the call."""
