@@ -130,25 +130,47 @@ __global__ __launch_bounds__(256) void census4_kernel(const uint8_t *__restrict_
     const int sh = x - xs;
     unsigned long long seg[WSZ];
 #pragma unroll
-    for (int r = 0; r < WSZ; r++)
+    for (int r = 0; r < WSZ; r++) {
         __builtin_memcpy(&seg[r], img + (size_t)(y + r) * W + xs, 8);
+        seg[r] >>= 8 * sh; // byte i + k of the segment = column k of pixel x + i's window
+    }
+    // The four pixels' comparisons run side by side in the four bytes of a dword (the sweeps' kernels are the
+    // budget; this one was 330 VALU instructions per thread with a compare and a select per bit).  Unsigned
+    // "centre < neighbour" per byte: t = (c | H) - (n & ~H) has no borrow between bytes and its bit 7 says
+    // c_low7 >= n_low7; where the top bits are equal the answer is ~t7, else it is the neighbour's top bit.
+    constexpr u32 Hb = 0x80808080u;
+    const u32 cen = (u32)(seg[M] >> (8 * M)), cenH = cen | Hb;
+    constexpr int NPOS = WSZ * WSZ - 1, NACC = NPOS / 8;
+    static_assert(NPOS % 8 == 0, "3x3 and 5x5 windows: 8 or 24 comparisons");
+    u32 acc[NACC] = {};
+    int pos = 0;
+#pragma unroll
+    for (int r = 0; r < WSZ; r++)
+#pragma unroll
+        for (int k = 0; k < WSZ; k++) {
+            if (r == M && k == M)
+                continue;
+            const u32 nb = (u32)(seg[r] >> (8 * k));
+            const u32 t = cenH - (nb & ~Hb);
+            const u32 lt = (~cen & nb) | (~(cen ^ nb) & ~t); // bit 7 of every byte: centre < neighbour
+            acc[pos / 8] = (acc[pos / 8] << 1) | ((lt >> 7) & 0x01010101u); // 8 bits per byte: nothing crosses a byte
+            pos++;
+        }
+    u32 code[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        if (x + i >= w)
-            break;
-        const int o = (i + sh) * 8; // bit offset of the window's first column
-        const u32 c = (u32)(seg[M] >> (o + 8 * M)) & 0xFFu;
-        u32 code = 0;
+        code[i] = 0;
 #pragma unroll
-        for (int r = 0; r < WSZ; r++)
+        for (int g = 0; g < NACC; g++)
+            code[i] = (code[i] << 8) | ((acc[g] >> (8 * i)) & 0xFFu); // first comparison = highest bit, as stereo_costs.cc:55
+    }
+    if (x + 4 <= w) {
+        __builtin_memcpy(out + x, code, 16); // one 16-byte store (4-byte aligned)
+    } else {
 #pragma unroll
-            for (int k = 0; k < WSZ; k++) {
-                if (r == M && k == M)
-                    continue;
-                const u32 v = (u32)(seg[r] >> (o + 8 * k)) & 0xFFu;
-                code = (code << 1) + (v > c ? 1u : 0u);
-            }
-        out[x + i] = code;
+        for (int i = 0; i < 4; i++)
+            if (x + i < w)
+                out[x + i] = code[i];
     }
 }
 
