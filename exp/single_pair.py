@@ -35,3 +35,7 @@ e.kernel_stats(); e.set_profiling(True)
 for _ in range(10): dev()
 s = e.kernel_stats()
 print("kernel ms per pair:", {k: round(v[0] / 10, 4) for k, v in s.items()}, "sum %.3f" % (sum(v[0] for v in s.values()) / 10))
+d = e.direction_stats()  # (cleared by the kernel_stats call above: run again for the split)
+for _ in range(10): dev()
+print("sweep ms per direction:", [round(ms / max(1, n), 4) for ms, n in e.direction_stats()])
+e.kernel_stats()
