@@ -1823,8 +1823,10 @@ static int ham_match(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *bs2, long n
     }
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st); // nothing of this call may still run when the next one regrows the buffers
         return fail(c, e == hipErrorOutOfMemory ? SGMX_ERR_OOM : SGMX_ERR_HIP, std::string("hamming match: ") + hipGetErrorString(e));
+    }
     *nptr = (size_t)total;
     if ((!idx && !records) || total == 0)
         return SGMX_OK;
@@ -1933,7 +1935,7 @@ int sgmx_match_hamming_thres_nt(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *
     unsigned long long *d_cnt = nullptr, total = 0;
     int *d_idx = nullptr;
     uint16_t *d_h = nullptr;
-    auto cleanup = [&]() {}; // (the buffers are the context's grow-only ones)
+    // (device buffers: the context's grow-only ones, nothing to release here)
     hipError_t e = ham_buffer(c, HAM_A, (size_t)n1 * ncodes + 4, (void **)&d_a);
     if (e == hipSuccess)
         e = ham_buffer(c, HAM_B, (size_t)n2 * ncodes + 4, (void **)&d_b);
@@ -1960,7 +1962,6 @@ int sgmx_match_hamming_thres_nt(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *
             std::free(*ham);
             *keys = nullptr;
             *ham = nullptr;
-            cleanup();
             return fail(c, SGMX_ERR_OOM, "host allocation failed");
         }
     }
@@ -1978,7 +1979,6 @@ int sgmx_match_hamming_thres_nt(sgmx_ctx *c, const uint8_t *bs1, const uint8_t *
         if (e == hipSuccess)
             e = e2;
     }
-    cleanup();
     if (e != hipSuccess) {
         std::free(*keys);
         std::free(*ham);
