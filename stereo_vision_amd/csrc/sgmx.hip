@@ -47,6 +47,7 @@ struct FastView {
     u32 *cl = nullptr, *cr = nullptr;
     uint8_t *E = nullptr;
     uint16_t *BL = nullptr, *SB = nullptr, *raw = nullptr;
+    uint16_t *BL2 = nullptr;     // second border ring (directions that run side by side, Agg2Args::fuse), or null
 };
 
 } // namespace
@@ -128,6 +129,9 @@ struct sgmx_ctx {
     void *d_BL = nullptr;  // border ring
     uint8_t *d_E = nullptr;     // fast path: num_paths byte volumes, [k][max_batch][h][w][Dp]
     uint16_t *d_SB = nullptr;   // fast path: border accumulator, same shape as d_BL
+    uint16_t *d_BL2 = nullptr;  // fast path: second border ring (two directions side by side in small launch groups)
+    hipStream_t aux_stream = nullptr; // the second of two directions that run side by side
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t bytes_E = 0;         // one pair of one direction
     uint16_t *d_raw = nullptr, *d_out = nullptr;
     size_t bytes_C = 0, bytes_S = 0, bytes_BL = 0;
@@ -174,7 +178,8 @@ void free_scratch(sgmx_ctx *c)
 {
     void *ptrs[] = {c->d_left, c->d_right, c->d_cl,  c->d_cr, c->d_C,  c->d_S,     c->d_BL,   c->d_raw,   c->d_out,
                     c->d_E,    c->d_SB,    c->d_C2,  c->d_sub, c->d_ld, c->d_rd,   c->d_label, c->d_size, c->d_states,
-                    c->d_left2, c->d_right2, c->d_out2, c->d_blur};
+                    c->d_left2, c->d_right2, c->d_out2, c->d_blur, c->d_BL2};
+    c->d_BL2 = nullptr;
     c->d_blur = nullptr;
     c->blur_cap = 0;
     for (void *p : ptrs)
@@ -252,6 +257,7 @@ int ensure_scratch(sgmx_ctx *c, int mode, int W, int H, hipStream_t st)
         c->bytes_E = npix * c->DpF;
         HIPCHK(c, hipMalloc((void **)&c->d_E, c->bytes_E * B * c->prm.num_paths));
         HIPCHK(c, hipMalloc((void **)&c->d_SB, c->bytes_BL * B));
+        HIPCHK(c, hipMalloc((void **)&c->d_BL2, c->bytes_BL * B));
     } else {
         HIPCHK(c, hipMalloc(&c->d_C, c->bytes_C * B));
         HIPCHK(c, hipMalloc(&c->d_S, c->bytes_S * B));
@@ -491,6 +497,7 @@ FastView ctx_view(const sgmx_ctx *c)
     v.bytes_BL = c->bytes_BL;
     v.cl = c->d_cl; v.cr = c->d_cr; v.E = c->d_E;
     v.BL = (uint16_t *)c->d_BL; v.SB = c->d_SB; v.raw = c->d_raw;
+    v.BL2 = c->d_BL2;
     return v;
 }
 
@@ -524,7 +531,8 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
     hipEvent_t chain = nullptr;
     if (c->profiling == SGMX_PROFILE_SWEEPS && hipEventCreate(&chain) == hipSuccess)
         (void)hipEventRecord(chain, st);
-    for (int k = 0; k < np; k++) {
+    // One direction sweep of the group on stream `on`: ring reads from `ring`, ring writes into `ring_out` when fuse == 2.
+    auto sweep = [&](int k, hipStream_t on, int fuse, uint16_t *ring, uint16_t *ring_out) -> hipError_t {
         Agg2Args a;
         a.w = v.w;
         a.h = v.h;
@@ -536,24 +544,49 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
         a.P2 = c->prm.penalty2;
         a.npaths = a.dy == 0 ? v.h : (a.dx == 0 || SGMX_WRAP ? v.w : v.w + v.h - 1); // (wrapped diagonals: w of them)
         a.npairs = n;
+        a.fuse = fuse;
+        a.BLout = ring_out;
         const int nwg = ((a.npaths + 15) / 16) * n; // 4 waves x 4 paths per workgroup
         const dim3 grid(8 * ((nwg + 7) / 8));       // 8 equal XCD chunks
         const size_t lds = 0;
         uint8_t *Ek = v.E + (size_t)k * v.bytes_E * v.cap;
-        ProfScope ps(c, SGMX_K_AGGREGATE, st, k);
+        ProfScope ps(c, SGMX_K_AGGREGATE, on, k);
+        switch (c->RP) {
+        case 1: return launch_agg3<1>(k == 0, pad, grid, on, v.cl, v.cr, Ek, ring, v.SB, a, lds);
+        case 2: return launch_agg3<2>(k == 0, pad, grid, on, v.cl, v.cr, Ek, ring, v.SB, a, lds);
+        case 4: return launch_agg3<4>(k == 0, pad, grid, on, v.cl, v.cr, Ek, ring, v.SB, a, lds);
+        case 8: return launch_agg3<8>(k == 0, pad, grid, on, v.cl, v.cr, Ek, ring, v.SB, a, lds);
+        case 12: return launch_agg3<12>(k == 0, pad, grid, on, v.cl, v.cr, Ek, ring, v.SB, a, lds);
+        default: return launch_agg3<16>(k == 0, pad, grid, on, v.cl, v.cr, Ek, ring, v.SB, a, lds);
+        }
+    };
+    // Small launch groups leave most of the chip idle during a sweep (one KITTI pair: 93 - 310 waves for 1 024 SIMDs,
+    // and the two horizontal sweeps are 1 237 dependent steps each).  There the diagonal directions 0 and 5 run side
+    // by side with the horizontal directions 1 and 6 that follow them (Agg2Args::fuse): the horizontal sweep on a
+    // second stream, writing the second ring, which then becomes the ring.  Not under profiling (the events of a
+    // class would overlap) and not for the entry point that allocates nothing (no second ring, no second stream).
+    // Measured (exp/small_groups.py, KITTI size): 1 / 2 / 4 / 8 / 12 pairs per call 1.06 / 1.11 / 1.34 / 1.89 / 2.53 ms
+    // -> 0.96 / 1.01 / 1.23 / 1.78 / 2.45; at 32 pairs, where a sweep fills the chip, side by side costs 1.7 %: hence
+    // the bound on the waves of the two launches together.
+    const long two = (long)n * (((v.h + 3) / 4) + ((v.w + 3) / 4));
+    const bool side_by_side = SGMX_FUSE && SGMX_WRAP && np == 8 && prof && !c->profiling && v.BL2 && c->aux_stream && two <= 6144;
+    uint16_t *ring = v.BL, *spare = v.BL2;
+    for (int k = 0; k < np; k++) {
         hipError_t le;
-        if (c->RP == 1)
-            le = launch_agg3<1>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
-        else if (c->RP == 2)
-            le = launch_agg3<2>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
-        else if (c->RP == 4)
-            le = launch_agg3<4>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
-        else if (c->RP == 8)
-            le = launch_agg3<8>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
-        else if (c->RP == 12)
-            le = launch_agg3<12>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
-        else
-            le = launch_agg3<16>(k == 0, pad, grid, st, v.cl, v.cr, Ek, v.BL, v.SB, a, lds);
+        if (side_by_side && (k == 0 || k == 5)) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, st));
+            HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            le = sweep(k + 1, c->aux_stream, 2, ring, spare);
+            if (le == hipSuccess)
+                le = sweep(k, st, 1, ring, nullptr);
+            HIPCHK(c, le);
+            HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
+            HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+            std::swap(ring, spare);
+            k++;
+        } else {
+            le = sweep(k, st, 0, ring, nullptr);
+        }
         if (chain) {
             hipEvent_t next = nullptr;
             if (hipEventCreate(&next) == hipSuccess) {
@@ -938,7 +971,9 @@ int sgmx_create(const sgmx_params *params, sgmx_ctx **out)
     c->RP = p.disp_range <= 32 ? 1 : (p.disp_range <= 64 ? 2 : (p.disp_range <= 128 ? 4 : (p.disp_range <= 256 ? 8 : (p.disp_range <= 384 ? 12 : 16))));
     c->DpF = 32 * c->RP;
     bool ok = hipSetDevice(p.device) == hipSuccess && hipStreamCreate(&c->own_stream) == hipSuccess &&
-              hipStreamCreate(&c->copy_stream) == hipSuccess &&
+              hipStreamCreate(&c->copy_stream) == hipSuccess && hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess && // (no implicit ordering with a caller's null stream)
+              hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) == hipSuccess &&
               // set-up of the entry point that allocates nothing: this device's address of the static scratch
               noalloc_scratch_for_device(p.device, &c->noalloc_scratch) == hipSuccess;
@@ -980,6 +1015,11 @@ void sgmx_destroy(sgmx_ctx *ctx)
         (void)hipEventDestroy(ctx->ev_scratch);
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->aux_stream)
+        (void)hipStreamDestroy(ctx->aux_stream);
+    for (hipEvent_t ev : {ctx->ev_fork, ctx->ev_join})
+        if (ev)
+            (void)hipEventDestroy(ev);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

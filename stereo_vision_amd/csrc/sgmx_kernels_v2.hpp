@@ -51,6 +51,9 @@ namespace sgmx {
 #define SGMX_E_AUX 2
 #endif
 constexpr int E_STORE_AUX = SGMX_E_AUX; // cache policy bits of a buffer store: 2 = nt
+#ifndef SGMX_FUSE
+#define SGMX_FUSE 1 // small launch groups: directions 0 / 1 and 5 / 6 side by side (0: A/B builds only)
+#endif
 #ifndef SGMX_WRAP
 #define SGMX_WRAP 1 // diagonal sweeps walk wrapped diagonals (0: one row per diagonal, A/B builds only)
 #endif
@@ -63,6 +66,15 @@ struct Agg2Args {
     int dx, dy;        // predecessor of (y,x) is (y-dy, x-dx)
     int P1, P2;
     int npaths, npairs;
+    // Two directions of one launch group side by side (small groups only, where a sweep leaves most of the chip idle):
+    // the horizontal direction k+1 starts on the image column where the diagonal direction k starts too, so its start
+    // values L_k = L_{k-1} + C are known without running direction k: L_{k+1} = L_{k-1} + 2 C there.
+    //   fuse = 1 (direction k): reads the ring, writes nothing into it (direction k+1 writes every border pixel
+    //            after it in the reference's order), and leaves the carry of its column starts to direction k+1;
+    //   fuse = 2 (direction k+1): start values BL + 2 C, carry 2 BL + C (its own and direction k's), ring reads from
+    //            BL, ring writes into BLout (direction k still reads BL).
+    int fuse;
+    uint16_t *BLout; // fuse = 2: the ring this launch writes; otherwise unused (writes go to BL)
 };
 
 template <bool B> struct BoolC { static constexpr bool value = B; };
@@ -351,12 +363,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     const int sBi = (a.dy == 0 ? a.dx : a.dy) * Dp * 2;
     const unsigned soB0 = sBi < 0 ? T * (unsigned)(-sBi) : 0u, sB = (unsigned)sBi;
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char *>(reinterpret_cast<u32 *>(BL) + (size_t)pair * ring) - soB0, 0, -1, 0x00020000);
+        reinterpret_cast<char *>(reinterpret_cast<u32 *>(a.fuse == 2 ? a.BLout : BL) + (size_t)pair * ring) - soB0, 0, -1, 0x00020000);
     const int bi0 = a.dy == 0 ? (g.y0 == 0 ? 0 : w) + g.x0 : 2 * w + (g.x0 == 0 ? 0 : h) + g.y0;
     const unsigned voB = (unsigned)((bi0 * (Dp / 2) + RP * q) * 4);
     const bool edge_store = g.edge && valid;
-    u32 *BLf = reinterpret_cast<u32 *>(BL) + (size_t)pair * ring + RP * q;
+    u32 *BLf = reinterpret_cast<u32 *>(BL) + (size_t)pair * ring + RP * q;   // ring reads
+    u32 *BLw = reinterpret_cast<u32 *>(a.fuse == 2 ? a.BLout : BL) + (size_t)pair * ring + RP * q; // ring writes
     u32 *SBf = reinterpret_cast<u32 *>(SB) + (size_t)pair * ring + RP * q;
+    const bool ringw = valid && a.fuse != 1; // this lane stores into the ring at all
+    const int xscol = a.dx > 0 ? 0 : w - 1;  // the image column paths of this direction start on
 
     const u32 P1p = (u32)a.P1 * 0x10001u, P2p = (u32)a.P2 * 0x10001u;
     int tl0 = g.x0 - RP * q;          // x - RP q at step 0 (WRAP: of the unwrapped column)
@@ -403,8 +418,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             for (int j = 0; j < RP; j++) {
                 prior[j] = pk_add(bl[j], c[j]);
                 sb[j] = pk_add(sb[j], bl[j]);
+                if (a.fuse == 2) { // L_{k-1} + 2 C; the carries of directions k and k+1: L_{k-1} + (L_{k-1} + C)
+                    sb[j] = pk_add(sb[j], prior[j]);
+                    prior[j] = pk_add(prior[j], c[j]);
+                }
             }
-            if (valid)
+            if (valid && !(a.fuse == 1 && g.x0 == xscol))
                 __builtin_memcpy(SBf + bo, sb, 4 * RP);
         }
 #pragma unroll
@@ -418,8 +437,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
         for (int m = 0; m < NW; m++)
             gstart[m] = (u32)a.P2 * 0x01010101u;
         buf_store_ev<RP>(rsE, voE, soE0, gstart);
-        if (valid)
-            __builtin_memcpy(BLf + bo, prior, 4 * RP);
+        if (ringw)
+            __builtin_memcpy(BLw + bo, prior, 4 * RP);
 #pragma unroll
         for (int j = 0; j < RP; j++)
             prior[j] = pk_sub_sat(0x70007000u, prior[j]); // L -> Q (pads: INF16 -> 0)
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
     }
     u32 *bl_last = nullptr; // the ring slot of the path's last pixel
     if constexpr (!WRAP)
-        bl_last = BLf + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
+        bl_last = BLw + (size_t)border_index(g.y0 + (len - 1) * a.dy, g.x0 + (len - 1) * a.dx, w, h) * (Dp / 2);
 
     unsigned soRp = soR0 + (1 + PF) * sR, soLp = soL0 + (1 + PF) * sL; // soffsets of the step PF ahead
     unsigned soE = soE0, soB = soB0;
@@ -615,7 +634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
 #pragma unroll
                     for (int j = 0; j < RP; j++)
                         sb[j] = pk_add(sb[j], bl[j]);
-                    if (valid)
+                    if (valid && a.fuse != 1) // (fuse = 1: a column start, its carry is direction k+1's to add)
                         __builtin_memcpy(SBf + bo, sb, 4 * RP);
                 }
             }
@@ -686,12 +705,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 4 ? 4
             }
         } else if (t < len) {
             buf_store_ev<RP>(rsE, voE, soE, eb);
-            if (valid) {
+            if (ringw) {
                 if constexpr (WRAP) {
                     if (wstart || wend) // first or last pixel of a diagonal
-                        __builtin_memcpy(BLf + (size_t)border_index(g.y0 + t * a.dy, xt, w, h) * (Dp / 2), Lv, 4 * RP);
+                        __builtin_memcpy(BLw + (size_t)border_index(g.y0 + t * a.dy, xt, w, h) * (Dp / 2), Lv, 4 * RP);
                 } else if (g.edge) // path along an image edge: every pixel feeds a later direction's start
-                    __builtin_memcpy(BLf + (size_t)border_index(g.y0 + t * a.dy, g.x0 + t * a.dx, w, h) * (Dp / 2), Lv, 4 * RP);
+                    __builtin_memcpy(BLw + (size_t)border_index(g.y0 + t * a.dy, g.x0 + t * a.dx, w, h) * (Dp / 2), Lv, 4 * RP);
                 else if (t == len - 1)
                     __builtin_memcpy(bl_last, Lv, 4 * RP);
             }

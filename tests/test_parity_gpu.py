@@ -389,6 +389,36 @@ def test_profiling_modes(oracle):
     e.close()
 
 
+@pytest.mark.parametrize("D,paths", [(64, 8), (16, 8), (130, 8), (64, 4)])
+def test_directions_side_by_side_equal_one_after_the_other(oracle, D, paths):
+    """Small launch groups run the diagonal directions 0 and 5 side by side with the horizontal directions 1 and 6 that
+    follow them (Agg2Args::fuse: analytic start values L_{k-1} + 2 C on the start column, a second border ring, a second
+    stream); under profiling the directions run one after the other.  Same disparities and the same summed costs, for
+    1..5 pairs per call, on the caller's null stream and on a stream of its own; against the oracle."""
+    import torch
+    H, W = 52, 170
+    pairs = [synth_pair(400 + i, H, W, 40) for i in range(5)]
+    want = [oracle.sgm_census(l, r, D, 5, 3, 60, paths, taps=True) for l, r in pairs]
+    side = torch.cuda.Stream()
+    for n in (1, 2, 5):
+        L = torch.from_numpy(np.stack([p[0] for p in pairs[:n]])).cuda()
+        R = torch.from_numpy(np.stack([p[1] for p in pairs[:n]])).cuda()
+        e = make(disp_range=D, window_sz=5, penalty1=3, penalty2=60, num_paths=paths, max_batch=n)
+        for mode, stream in ((0, 0), (1, 0), (0, side.cuda_stream)):  # side by side / one after the other / own stream
+            e.set_profiling(mode)
+            out = torch.full((n, H, W), -1, dtype=torch.int16, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(2):
+                e.compute_device(L.data_ptr(), R.data_ptr(), out.data_ptr(), n, W, H, stream)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().view(np.uint16)
+            for k in range(n):
+                assert np.array_equal(got[k], want[k]["disp"]), "n=%d mode=%d pair %d" % (n, mode, k)
+            assert np.array_equal(e.stages(H, W, n - 1)["S"], want[n - 1]["S"])
+            e.kernel_stats()
+        e.close()
+
+
 def test_taps_address_the_last_launch_group(oracle):
     """The stage taps reach the last launch group only; sgmx_last_launch_group says which pairs of the call those
     are.  5 pairs with max_batch 2 run as 2 + 2 + 1: tap index 0 is pair 4 of the call."""
