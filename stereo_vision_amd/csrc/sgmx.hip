@@ -565,11 +565,14 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
     // by side with the horizontal directions 1 and 6 that follow them (Agg2Args::fuse): the horizontal sweep on a
     // second stream, writing the second ring, which then becomes the ring.  Not under profiling (the events of a
     // class would overlap) and not for the entry point that allocates nothing (no second ring, no second stream).
-    // Measured (exp/small_groups.py, KITTI size): 1 / 2 / 4 / 8 / 12 pairs per call 1.06 / 1.11 / 1.34 / 1.89 / 2.53 ms
-    // -> 0.96 / 1.01 / 1.23 / 1.78 / 2.45; at 32 pairs, where a sweep fills the chip, side by side costs 1.7 %: hence
-    // the bound on the waves of the two launches together.
+    // Measured (exp/small_groups.py, KITTI size): 1 / 2 / 4 / 6 pairs per call 1.06 / 1.11 / 1.34 / 1.55 ms
+    // -> 0.96 / 1.01 / 1.23 / 1.45; 3840x2160 D=256 one pair 8.92 -> 7.97 ms.  Once the two launches together come
+    // near the waves the chip holds it stops paying and then costs (KITTI, 32 pairs: -1.7 %; 3840x2160, 2 or 3 pairs:
+    // -1 % / -4 %; 1241x376 D=270, 6 pairs: -2 %): bounded to 0.7 of the resident waves (1 024 SIMDs x the kernels'
+    // waves per SIMD).
     const long two = (long)n * (((v.h + 3) / 4) + ((v.w + 3) / 4));
-    const bool side_by_side = SGMX_FUSE && SGMX_WRAP && np == 8 && prof && !c->profiling && v.BL2 && c->aux_stream && two <= 6144;
+    const long resident = 1024L * (c->RP <= 4 ? 4 : (c->RP == 8 ? (pad ? 3 : 4) : 2));
+    const bool side_by_side = SGMX_FUSE && SGMX_WRAP && np == 8 && prof && !c->profiling && v.BL2 && c->aux_stream && 10 * two <= 7 * resident;
     uint16_t *ring = v.BL, *spare = v.BL2;
     for (int k = 0; k < np; k++) {
         hipError_t le;
