@@ -12,7 +12,7 @@ import csv, glob
 out = "$out"
 f = glob.glob(out + "/float/*/*kernel_stats.csv")[0]
 with open(out + "/float_kernel_stats.txt", "w") as g:
-    g.write(open(out + "/float.log").read().strip().splitlines()[-1] + "\n")
+    g.write([l for l in open(out + "/float.log").read().splitlines() if l.startswith("float volume")][-1] + "   (under the profiler)\n")
     for r in csv.DictReader(open(f)):
         if "sgmx" in r["Name"]:
             g.write("%-70s calls %4s  total %10.3f ms  avg %9.1f us\n" % (r["Name"].split("(")[0][-70:], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
