@@ -311,6 +311,50 @@ def hamming_library_leg(sv, device, na=100000, nb=4096, ncodes=16, ht=44):
     return out
 
 
+def sequence_files_leg(npairs=1056, threads=16):
+    """BASELINE.json configs[2] file to file on this rank's GPU: `sgm_batch census` (the counterpart of
+    scripts/run_sgm_batch_census.py:14-34: PNG pairs in, disparities/ and norm_hist/ PNGs out) on npairs synthetic KITTI-size
+    pairs (64 distinct files, the rest hard links: the same decode work per file), groups of 32, `threads` host threads.
+    A child process; bounded by the host's PNG work, not by the GPU."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from PIL import Image
+    exe = os.path.join(ROOT, "stereo_vision_amd", "bin", "sgm_batch")
+    root = tempfile.mkdtemp(prefix="sgmx_seq_")
+    try:
+        for d in ("image_0", "image_1"):
+            os.makedirs(os.path.join(root, d))
+        base = [synthetic_pair(100 + i, 376, 1241, 100) for i in range(8)]
+        uniq = 64
+        for i in range(npairs):
+            for d, k in (("image_0", 0), ("image_1", 1)):
+                dst = os.path.join(root, d, "%06d_10.png" % i)
+                if i < uniq:
+                    Image.fromarray(np.roll(base[i % 8][k], i, axis=0)).save(dst, compress_level=1)
+                else:
+                    os.link(os.path.join(root, d, "%06d_10.png" % (i % uniq)), dst)
+        out = {"workload": "%d KITTI-size PNG pairs, D=128, wsz=5, 8 paths, P1=3, P2=60; sgm_batch census --batch 32 --threads %d" % (npairs, threads)}
+        for name, extra in (("pairs_per_s_with_png_outputs", []), ("pairs_per_s_decode_only", ["--no-write"])):
+            cmd = [exe, "census", root + "/image_0", root + "/image_1", root + "/out", "3", "60", "--disp-range", "128", "--window-sz", "5",
+                   "--batch", "32", "--threads", str(threads)] + extra
+            t = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            dt = time.perf_counter() - t
+            m = re.search(r"pairs: (\d+)  ranks: (\d+)  wall: ([0-9.]+) s  ([0-9.]+) pairs/s  checksum xor: ([0-9a-f]{16})", r.stdout)
+            if r.returncode != 0 or not m:
+                raise RuntimeError("sgm_batch failed: " + r.stderr[-300:])
+            out[name] = float(m.group(4))
+            out[name.replace("pairs_per_s", "process_wall_s")] = round(dt, 3)
+            out["checksum_xor"] = m.group(5)
+        out["host_threads"] = threads
+        out["host_cores_available"] = len(os.sched_getaffinity(0))
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -571,6 +615,7 @@ def main():
                 torch.cuda.empty_cache()
                 out["secondary"].update(leg("other_configs", lambda: other_configs(sv, torch, local_rank)))
                 out["secondary"]["hamming_library"] = leg("hamming_library", lambda: hamming_library_leg(sv, local_rank))
+                out["secondary"]["sequence_files"] = leg("sequence_files", sequence_files_leg)
         print(json.dumps(out), flush=True)
 
     if use_dist:
