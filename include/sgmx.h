@@ -128,8 +128,8 @@ SGMX_API int sgmx_compute_census_u8_dev(sgmx_ctx *ctx, int n, const uint8_t *d_l
  * Limits: the volume-free formulation only (penalty2 <= 255, no SGMX_FLAG_MATERIALIZE), WTA row tables within
  * 64 KiB (width up to ~3 900), and one pair's buffers must fit the array.  One pair needs (h w Dp) bytes per
  * direction (h, w = cropped size, Dp = disp_range rounded up to 32, 64, 128, 256, 384 or 512) plus about 10 bytes
- * per pixel: 384x288 at D=16 takes 15.1 MB with 4 paths and 28.9 MB with 8 (4 resp. 2 pairs per launch group fit);
- * 288x200 at D=64, 8 paths 29.4 MB; 640x480 at D=64, 8 paths 159 MB: too large -> SGMX_ERR_INVALID_ARG with the byte
+ * per pixel: 384x288 at D=16 takes 15.2 MB with 4 paths and 29.0 MB with 8 (4 resp. 2 pairs per launch group fit);
+ * 288x200 at D=64, 8 paths 29.5 MB; 640x480 at D=64, 8 paths 159 MB: too large -> SGMX_ERR_INVALID_ARG with the byte
  * count (use sgmx_compute_census_u8_dev).  n pairs run in launch groups of as many pairs as fit (at most max_batch).
  * Under stream capture (hipStreamBeginCapture on `stream`, any capture mode) the call records its memsets and
  * kernels into the graph and nothing else: tests/test_zz_no_alloc.py captures two calls in global capture mode,

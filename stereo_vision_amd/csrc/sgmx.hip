@@ -564,7 +564,8 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
     // and the two horizontal sweeps are 1 237 dependent steps each).  There the diagonal directions 0 and 5 run side
     // by side with the horizontal directions 1 and 6 that follow them (Agg2Args::fuse): the horizontal sweep on a
     // second stream, writing the second ring, which then becomes the ring.  Not under profiling (the events of a
-    // class would overlap) and not for the entry point that allocates nothing (no second ring, no second stream).
+    // class would overlap).  The fork and the join are events between the two streams, which a stream capture
+    // records as branches of the graph (the entry point that allocates nothing runs this way too).
     // Measured (exp/small_groups.py, KITTI size): 1 / 2 / 4 / 6 pairs per call 1.06 / 1.11 / 1.34 / 1.55 ms
     // -> 0.96 / 1.01 / 1.23 / 1.45; 3840x2160 D=256 one pair 8.92 -> 7.97 ms.  Once the two launches together come
     // near the waves the chip holds it stops paying and then costs (KITTI, 32 pairs: -1.7 %; 3840x2160, 2 or 3 pairs:
@@ -572,7 +573,7 @@ int run_fast(sgmx_ctx *c, const FastView &v, int n, uint16_t *d_disp, hipStream_
     // waves per SIMD).
     const long two = (long)n * (((v.h + 3) / 4) + ((v.w + 3) / 4));
     const long resident = 1024L * (c->RP <= 4 ? 4 : (c->RP == 8 ? (pad ? 3 : 4) : 2));
-    const bool side_by_side = SGMX_FUSE && SGMX_WRAP && np == 8 && prof && !c->profiling && v.BL2 && c->aux_stream && 10 * two <= 7 * resident;
+    const bool side_by_side = SGMX_FUSE && SGMX_WRAP && np == 8 && !c->profiling && v.BL2 && c->aux_stream && 10 * two <= 7 * resident;
     uint16_t *ring = v.BL, *spare = v.BL2;
     for (int k = 0; k < np; k++) {
         hipError_t le;
@@ -1083,7 +1084,7 @@ int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *c, int n, const uint8_t *d_left
                  b_raw = nfull * 2;
     const int np = c->prm.num_paths;
     struct Layout {
-        size_t cl, cr, raw, E, BL, SB, total;
+        size_t cl, cr, raw, E, BL, SB, BL2, total;
     };
     auto layout = [&](size_t g) {
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1095,6 +1096,7 @@ int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *c, int n, const uint8_t *d_left
         L.E = off, off = up(off + g * b_E * np);
         L.BL = off, off = up(off + g * b_ring);
         L.SB = off, off = up(off + g * b_ring);
+        L.BL2 = off, off = up(off + g * b_ring); // second ring: two directions side by side in small launch groups
         L.total = off;
         return L;
     };
@@ -1122,6 +1124,7 @@ int sgmx_compute_census_u8_dev_noalloc(sgmx_ctx *c, int n, const uint8_t *d_left
     v.E = base + lay.E;
     v.BL = reinterpret_cast<uint16_t *>(base + lay.BL);
     v.SB = reinterpret_cast<uint16_t *>(base + lay.SB);
+    v.BL2 = reinterpret_cast<uint16_t *>(base + lay.BL2);
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n; i += g) {
         const int k = n - i < g ? n - i : g;

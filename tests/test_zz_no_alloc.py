@@ -34,7 +34,7 @@ def test_noalloc_equals_dev_entry_point_two_calls_second_smaller(oracle):
     import torch
     import stereo_vision_amd as sv
     assert sv._lib.load().sgmx_noalloc_scratch_bytes() == 64 << 20
-    # first call: 3 pairs of 288x200 at D=64, 8 paths, in launch groups of 2 (29.4 MB per pair: 2 fit the 64 MiB, and
+    # first call: 3 pairs of 288x200 at D=64, 8 paths, in launch groups of 2 (29.5 MB per pair: 2 fit the 64 MiB, and
     # max_batch is 2 as well)
     big = [synth_pair(700 + i, 200, 288, 50) for i in range(3)]
     got, want = _both(sv, torch, big, 64, 8, 2)
